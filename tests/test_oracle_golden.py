@@ -1,0 +1,105 @@
+"""The CPU oracle (oracle/line_sted_oracle.py) against golden vectors produced
+by the real reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import line_sted_oracle as orc
+from conftest import max_rel
+
+PSF_TOL = 1e-12     # PSF arrays: same arithmetic, float64
+FIT_TOL = 1e-10     # Gaussian-fit widths: same MINPACK iteration restated (oracle/minpack_lm.py)
+
+
+def _parse(key):
+    t, s, e, d, p = key.split('_')
+    return t, float(s[1:]), float(e[1:]), float(d[1:]), int(p[1:])
+
+
+def test_g1_psf_report(golden):
+    g = golden('g1_psf_report')
+    for key in g['cases']:
+        key = str(key)
+        psf_type, steps, exc, dep, pulses = _parse(key)
+        r = orc.psf_report(psf_type, exc, dep, steps, pulses)
+        sc = g[key + '/scalars']
+        assert r['resolution_improvement_descanned'] == pytest.approx(sc[0], rel=FIT_TOL)
+        if psf_type == 'line':
+            assert r['resolution_improvement_rescanned'] == pytest.approx(sc[1], rel=FIT_TOL)
+            assert r['line_rescan_ratio'] == int(g[key + '/ratio'][1])
+        assert r['excitation_dose'] == pytest.approx(sc[2], rel=1e-12)
+        assert r['depletion_dose'] == pytest.approx(sc[3], rel=1e-12, abs=1e-300)
+        assert r['expected_emission'] == pytest.approx(sc[4], rel=1e-12)
+        if pulses != 1:
+            continue
+        n = r['psfs']['sted'].shape[1]
+        for k, v in r['psfs'].items():
+            if key + '/psf/' + k in g:
+                assert max_rel(v, g[key + '/psf/' + k]) < PSF_TOL, (key, k)
+            else:
+                assert max_rel(v[0, n // 2, :], g[key + '/row/' + k]) < PSF_TOL, (key, k)
+                assert max_rel(v[0, :, n // 2], g[key + '/col/' + k]) < PSF_TOL, (key, k)
+
+
+def test_g2_get_width(golden):
+    g = golden('g2_get_width')
+    for row, fit, (n, w) in zip(g['rows'], g['fits'], g['n_and_width']):
+        n = int(n)
+        s, f = orc.get_width(row[:n])
+        assert abs(s) == pytest.approx(abs(w), rel=FIT_TOL)
+        assert max_rel(f, fit[:n]) < 1e-6
+
+
+def test_g4_conv_conventions(golden):
+    g = golden('g4_conv')
+    for name in ('odd', 'even', 'row', 'big', 'two'):
+        x, psfs, y = g[name + '/x'], g[name + '/psfs'], g[name + '/y']
+        d = orc.Deconvolver(list(psfs))
+        H = d.H(x)
+        for i in range(len(psfs)):
+            assert max_rel(H[i], g[name + '/H'][i]) < 1e-13
+            # the FFT restatement and the literal double loop agree
+            direct = orc.conv_same_direct(x, psfs[i])
+            assert max_rel(np.maximum(direct, 0), g[name + '/H'][i]) < 1e-13
+        assert max_rel(d.H_t(list(y), normalize=False), g[name + '/Ht_raw']) < 1e-13
+        assert max_rel(d.H_t(list(y)), g[name + '/Ht']) < 1e-12
+        assert max_rel(d.H_t_normalization, g[name + '/norm']) < 1e-13
+
+
+@pytest.mark.parametrize('run,ks', [('rings_point_1p5x', (1, 2, 5, 20, 100)),
+                                    ('rings_line4_2p0x', (1, 5, 20)),
+                                    ('cat_line1_1p0x', (5,))])
+def test_g5_simulate_and_rl(golden, run, ks):
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    psf_set = list(psfs[str(g[run + '/psf_key'])])
+    obj = objs[str(g[run + '/object'])].astype(np.float64)
+    d = orc.Deconvolver(psf_set)
+    d.create_data_from_object(obj, total_brightness=5e10,
+                              noisy_measurement=list(g[run + '/noisy']))
+    for i in range(len(psf_set)):
+        assert max_rel(d.noiseless_measurement[i], g[run + '/noiseless'][i]) < 1e-13
+    for k in range(1, max(ks) + 1):
+        d.iterate()
+        if k in ks:
+            ref = g[run + '/estimate_%d' % k]
+            err = np.abs(d.estimate - ref) / np.abs(ref)      # pixelwise
+            assert err.max() < 1e-9, (run, k, err.max())
+    assert max_rel(d.H_t_normalization, g[run + '/norm']) < 1e-13
+
+
+def test_g5_numpy_legacy_poisson_is_what_the_reference_draws(golden):
+    """create_data_from_object(random_seed=0) -> np.random.seed + np.random.poisson
+    on the noiseless images, view by view (ref:508-511)."""
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    run = 'rings_point_1p5x'
+    d = orc.Deconvolver(list(psfs[str(g[run + '/psf_key'])]))
+    d.create_data_from_object(objs['rings'].astype(np.float64), 5e10, random_seed=0)
+    # identical lambda to 1e-13 -> identical draws except where a PTRS
+    # accept/reject decision sits within rounding; allow a handful
+    same = d.noisy_measurement[0] == g[run + '/noisy'][0]
+    assert same.mean() > 0.999
+
+
+def test_g9_logarithmic_progress(golden):
+    g = golden('g9_progress')
+    for n in (0, 1, 2, 3, 5, 17, 1025):
+        assert list(g['n%d' % n]) == orc.logarithmic_progress_flags(n)
