@@ -1,0 +1,244 @@
+// conv_kernels.hpp -- workgroup bodies of the FFT-convolution / Richardson-Lucy
+// kernels.  Shared by the HIP kernels (rlsted_kernels.hip) and by the host
+// emulator used in the CPU tests (tests/emu/emu.cpp).
+//
+// Reference semantics implemented here (figure_generation/line_sted_tools.py):
+//   H   :567-577  per PSF: zero padded 'same' convolution, clamp negatives to 0
+//   H_t :579-594  sum over PSFs of the same convolution (un-flipped PSF), each
+//                 term clamped, then divided by H_t(ones)
+//   iterate :520-531  est *= H_t(measurement / H(est))
+//
+// Data layout (all row-major, contiguous):
+//   images   real  [img][ny][nx]
+//   spectra  cx<T> [img][ny][pitch]   row-transformed half spectra, Kx = Lx/2+1
+//                                     valid columns, pitch = Kx rounded up to 8
+//   psf_hat  cx<T> [view][Ly][pitch]  2-D spectrum of the PSF wrapped around the
+//                                     origin, pre-scaled by 1/(Ly*Lx)
+// A 2-D circular convolution of size Ly x Lx with Ly >= ny + Py/2, Lx >= nx +
+// Px/2 restricted to rows < ny, columns < nx equals the zero padded 'same'
+// convolution exactly (DESIGN.md "wrap-free sizes").
+#pragma once
+#include "fft_core.hpp"
+
+namespace rl {
+
+// ------------------------------ column pass --------------------------------
+// For one tile of C spectrum columns: forward FFT along y (rows >= ny are
+// zero), multiply by psf_hat, inverse FFT along y, keep rows < ny.
+template <typename T>
+struct ColParams {
+    const cx<T>* in;        // [n_in_img][ny][pitch]
+    cx<T>* out;             // [gridDim.y][ny][pitch]
+    const cx<T>* psf_hat;   // [V][Ly][pitch]
+    const cx<T>* tw;        // [Ly] exp(-2 pi i m / Ly)
+    int ny, kx, pitch;
+    int V;                  // views per frame; blockIdx.y = frame*V + view
+    int in_sb, in_sv;       // input image index = frame*in_sb + view*in_sv
+};
+
+template <class Cfg, int C, typename T, class Sync>
+RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    constexpr int NP = Cfg::NP;
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    const int c = tid % C, t = tid / C;
+    const int col = bx * C + c;
+    const bool colok = col < p.kx;
+    const int frame = by / p.V, view = by % p.V;
+    const size_t img = (size_t)p.ny * p.pitch;
+    const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
+    cx<T>* __restrict__ out = p.out + (size_t)by * img;
+    const cx<T>* __restrict__ ph = p.psf_hat + (size_t)view * Cfg::L * p.pitch;
+    LdsView<T, C> view_lds{lds + c};
+
+    cx<T> v[VMAX];
+    {   // forward pass 0 operands straight from global memory
+        using F0 = PassInfo<Cfg, false, 0>;
+#pragma unroll
+        for (int nb = 0; nb < F0::NB; ++nb) {
+            const int j = t + nb * Cfg::T;
+#pragma unroll
+            for (int r = 0; r < F0::R; ++r) {
+                const int i = j + r * F0::NBF;
+                cx<T> x = mk<T>((T)0, (T)0);
+                if (j < F0::NBF && colok && i < p.ny) x = in[(size_t)i * p.pitch + col];
+                v[nb * F0::R + r] = x;
+            }
+        }
+    }
+    run_passes<Cfg, false, 0, true>(v, t, view_lds, p.tw, sync);
+    {   // pointwise multiply in registers (element index of the last forward pass)
+        using FL = PassInfo<Cfg, false, NP - 1>;
+#pragma unroll
+        for (int nb = 0; nb < FL::NB; ++nb) {
+            const int j = t + nb * Cfg::T;
+#pragma unroll
+            for (int r = 0; r < FL::R; ++r) {
+                const int i = j + r * FL::NBF;
+                if (j < FL::NBF && colok) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[(size_t)i * p.pitch + col]);
+            }
+        }
+    }
+    run_passes<Cfg, true, 0, true>(v, t, view_lds, p.tw, sync);
+    {
+        using IL = PassInfo<Cfg, true, NP - 1>;
+#pragma unroll
+        for (int nb = 0; nb < IL::NB; ++nb) {
+            const int j = t + nb * Cfg::T;
+#pragma unroll
+            for (int r = 0; r < IL::R; ++r) {
+                const int i = j + r * IL::NBF;
+                if (j < IL::NBF && colok && i < p.ny) out[(size_t)i * p.pitch + col] = v[nb * IL::R + r];
+            }
+        }
+    }
+}
+
+// -------------------------------- row pass ---------------------------------
+// Two real image rows (2p, 2p+1) ride through one complex transform of length
+// Lx (real row in .re, the next row in .im).  Depending on MODE the body does
+//   [inverse rows of V spectra -> clamp -> accumulate] -> pointwise -> [forward]
+// entirely in LDS/registers.
+enum RowMode {
+    ROW_FWD = 0,      // spec_out[f]      = rowFFT(src[f] * scale[f])
+    ROW_INV = 1,      // dst[f*V+v]       = max(rowIFFT(spec_in[f*V+v]), 0)          (H output / noiseless)
+    ROW_RATIO = 2,    // spec_out[f*V+v]  = rowFFT(meas[f*V+v] / max(rowIFFT(spec_in[f*V+v]), 0))
+    ROW_UPDATE = 3,   // acc = sum_v max(rowIFFT(spec_in[f*V+v]),0); est[f] *= acc/norm; spec_out[f] = rowFFT(est[f])
+    ROW_ADJ = 4       // dst[f] = sum_v max(rowIFFT(spec_in[f*V+v]),0) (/ norm if norm != nullptr)
+};
+
+template <typename T>
+struct RowParams {
+    const cx<T>* spec_in;   // [..][ny][pitch]
+    cx<T>* spec_out;        // [..][ny][pitch]
+    const T* src;           // ROW_FWD: [frames][ny][nx]; ROW_RATIO: measurement [frames*V][ny][nx]
+    T* dst;                 // ROW_INV / ROW_ADJ output; ROW_UPDATE: estimate (read + written)
+    const T* norm;          // [ny][nx] H_t(ones) (ROW_UPDATE; optional for ROW_ADJ)
+    const T* scale;         // ROW_FWD: per-frame multiplier or nullptr
+    const cx<T>* tw;        // [Lx]
+    int ny, nx, pitch, V;
+};
+
+template <class Cfg, int Q, int MODE, typename T, class Sync>
+RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    constexpr int NP = Cfg::NP, L = Cfg::L, TT = Cfg::T;
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    const int q = tid / TT, t = tid % TT;
+    const int r0 = 2 * (bx * Q + q), r1 = r0 + 1;
+    const bool ok0 = r0 < p.ny, ok1 = r1 < p.ny;
+    const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
+    LdsView<T, 1> view_lds{lds + q * LdsLen<L>::value};
+
+    // element index held in register slot (nb, r) after an inverse / before a forward
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    using F0 = PassInfo<Cfg, false, 0>;
+    static_assert(IL::R == F0::R && IL::NB == F0::NB, "inverse must end on the forward's first radix");
+    constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
+
+    cx<T> v[VMAX];
+    cx<T> acc[MODE == ROW_UPDATE || MODE == ROW_ADJ ? NB * R : 1];
+
+    if constexpr (MODE != ROW_FWD) {
+        constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
+        const int nview = MULTI ? p.V : 1;
+        if constexpr (MULTI) {
+#pragma unroll
+            for (int s = 0; s < NB * R; ++s) acc[s] = mk<T>((T)0, (T)0);
+        }
+        for (int vw = 0; vw < nview; ++vw) {
+            const size_t im = MULTI ? (size_t)by * p.V + vw : (size_t)by;
+            const cx<T>* __restrict__ sp = p.spec_in + im * simg;
+            sync();   // LDS free
+            // pack the two half spectra into one Hermitian-free complex row
+            for (int k = t; k <= L / 2; k += TT) {
+                cx<T> A = mk<T>((T)0, (T)0), B = mk<T>((T)0, (T)0);
+                if (ok0) A = sp[(size_t)r0 * p.pitch + k];
+                if (ok1) B = sp[(size_t)r1 * p.pitch + k];
+                view_lds.at(k) = mk<T>(A.re - B.im, A.im + B.re);
+                if (k > 0 && k < L / 2) view_lds.at(L - k) = mk<T>(A.re + B.im, B.re - A.im);
+            }
+            sync();
+            run_passes<Cfg, true, 0, false>(v, t, view_lds, p.tw, sync);
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int s = 0; s < NB * R; ++s) {
+                    acc[s].re += v[s].re > (T)0 ? v[s].re : (T)0;
+                    acc[s].im += v[s].im > (T)0 ? v[s].im : (T)0;
+                }
+            }
+        }
+    }
+
+    // pointwise stage on elements i = j + r*NBF (column index), rows r0 (.re), r1 (.im)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = t + nb * TT;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = nb * R + r;
+            const int i = j + r * NBF;
+            const bool inx = (j < NBF) && (i < p.nx);
+            cx<T> z = mk<T>((T)0, (T)0);
+            if constexpr (MODE == ROW_FWD) {
+                const T sc = p.scale ? p.scale[by] : (T)1;
+                const T* __restrict__ src = p.src + (size_t)by * rimg;
+                if (inx && ok0) z.re = src[(size_t)r0 * p.nx + i] * sc;
+                if (inx && ok1) z.im = src[(size_t)r1 * p.nx + i] * sc;
+            } else if constexpr (MODE == ROW_INV) {
+                T* __restrict__ dst = p.dst + (size_t)by * rimg;
+                if (inx && ok0) dst[(size_t)r0 * p.nx + i] = v[s].re > (T)0 ? v[s].re : (T)0;
+                if (inx && ok1) dst[(size_t)r1 * p.nx + i] = v[s].im > (T)0 ? v[s].im : (T)0;
+            } else if constexpr (MODE == ROW_RATIO) {
+                const T* __restrict__ meas = p.src + (size_t)by * rimg;
+                if (inx && ok0) z.re = meas[(size_t)r0 * p.nx + i] / (v[s].re > (T)0 ? v[s].re : (T)0);
+                if (inx && ok1) z.im = meas[(size_t)r1 * p.nx + i] / (v[s].im > (T)0 ? v[s].im : (T)0);
+            } else if constexpr (MODE == ROW_UPDATE) {
+                T* __restrict__ est = p.dst + (size_t)by * rimg;
+                if (inx && ok0) {
+                    const size_t o = (size_t)r0 * p.nx + i;
+                    z.re = est[o] * (acc[s].re / p.norm[o]);
+                    est[o] = z.re;
+                }
+                if (inx && ok1) {
+                    const size_t o = (size_t)r1 * p.nx + i;
+                    z.im = est[o] * (acc[s].im / p.norm[o]);
+                    est[o] = z.im;
+                }
+            } else if constexpr (MODE == ROW_ADJ) {
+                T* __restrict__ dst = p.dst + (size_t)by * rimg;
+                if (inx && ok0) {
+                    const size_t o = (size_t)r0 * p.nx + i;
+                    dst[o] = p.norm ? acc[s].re / p.norm[o] : acc[s].re;
+                }
+                if (inx && ok1) {
+                    const size_t o = (size_t)r1 * p.nx + i;
+                    dst[o] = p.norm ? acc[s].im / p.norm[o] : acc[s].im;
+                }
+            }
+            v[s] = z;
+        }
+    }
+
+    if constexpr (MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE) {
+        run_passes<Cfg, false, 0, true>(v, t, view_lds, p.tw, sync);
+        // natural-order spectrum to LDS, then split it into the two rows' half spectra
+        using FL = PassInfo<Cfg, false, NP - 1>;
+        sync();
+#pragma unroll
+        for (int nb = 0; nb < FL::NB; ++nb) {
+            const int j = t + nb * TT;
+            if (j < FL::NBF) {
+#pragma unroll
+                for (int r = 0; r < FL::R; ++r) view_lds.at(j + r * FL::NBF) = v[nb * FL::R + r];
+            }
+        }
+        sync();
+        cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg;
+        for (int k = t; k <= L / 2; k += TT) {
+            const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
+            if (ok0) so[(size_t)r0 * p.pitch + k] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
+            if (ok1) so[(size_t)r1 * p.pitch + k] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+        }
+    }
+}
+
+}  // namespace rl

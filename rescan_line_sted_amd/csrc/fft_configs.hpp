@@ -1,0 +1,45 @@
+// fft_configs.hpp -- the supported transform lengths and their geometry.
+// Length L, T threads per transform, forward radix list (the inverse runs it
+// reversed); C = spectrum columns per workgroup in the column kernel and
+// Q = row pairs per workgroup in the row kernels, for f32 / f64.
+// LDS per workgroup = C * (L*9/8 + 1) * sizeof(complex).
+#pragma once
+#include "fft_core.hpp"
+
+namespace rl {
+
+template <int L>
+struct CfgFor;
+
+template <>
+struct CfgFor<64> {   // unit-test size
+    using Cfg = FftCfg<64, 8, 8, 8>;
+    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+};
+template <>
+struct CfgFor<192> {  // 128 + 53
+    using Cfg = FftCfg<192, 48, 4, 6, 8>;
+    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+};
+template <>
+struct CfgFor<256> {  // 160 + 53
+    using Cfg = FftCfg<256, 64, 4, 8, 8>;
+    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+};
+template <>
+struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
+    using Cfg = FftCfg<576, 72, 8, 8, 9>;
+    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+};
+template <>
+struct CfgFor<1152> { // 1024 + 53
+    using Cfg = FftCfg<1152, 144, 8, 9, 16>;
+    static constexpr int C32 = 4, C64 = 4, Q32 = 4, Q64 = 4;
+};
+template <>
+struct CfgFor<2304> { // 2048 + 53
+    using Cfg = FftCfg<2304, 256, 9, 16, 16>;
+    static constexpr int C32 = 4, C64 = 2, Q32 = 2, Q64 = 2;
+};
+
+}  // namespace rl

@@ -1,0 +1,268 @@
+// fft_core.hpp -- register/LDS Stockham FFT building blocks for gfx950.
+//
+// One length-L complex transform is executed by T cooperating threads.  Each
+// pass p has radix R_p: L/R_p butterflies, thread t owns butterflies
+// j = t + nb*T.  A butterfly reads elements j + r*L/R (coalesced across t),
+// applies the inter-pass twiddles, does an R-point DFT in registers and
+// scatters to j0 + r*Ns (Stockham autosort, natural order in and out).
+// The first pass takes its inputs from registers and the last pass leaves its
+// outputs in registers, at element index j + r*L/R in both cases, so
+//   * global loads/stores are issued by the first/last pass directly, and
+//   * an inverse transform whose first radix equals the previous forward's
+//     last radix (radix list reversed) chains on with no LDS exchange:
+//     FFT -> pointwise -> IFFT and IFFT -> pointwise -> FFT stay in registers.
+//
+// The bodies are plain templates usable from device code and from the host
+// emulator in tests/emu (same index logic, run under pthread barriers).
+#pragma once
+
+#if defined(__HIPCC__)
+#define RL_HD __host__ __device__ __forceinline__
+#else
+#define RL_HD inline __attribute__((always_inline))
+#endif
+
+namespace rl {
+
+template <typename T>
+struct cx {
+    T re, im;
+};
+
+template <typename T>
+RL_HD cx<T> mk(T a, T b) {
+    cx<T> r;
+    r.re = a;
+    r.im = b;
+    return r;
+}
+template <typename T>
+RL_HD cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.re + b.re, a.im + b.im); }
+template <typename T>
+RL_HD cx<T> operator-(cx<T> a, cx<T> b) { return mk<T>(a.re - b.re, a.im - b.im); }
+template <typename T>
+RL_HD cx<T> cmul(cx<T> a, cx<T> b) {
+    return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+template <typename T>
+RL_HD cx<T> scale(cx<T> a, T s) { return mk<T>(a.re * s, a.im * s); }
+// multiply by -i (forward transforms) or +i (inverse transforms)
+template <bool INV, typename T>
+RL_HD cx<T> rot90(cx<T> a) { return INV ? mk<T>(-a.im, a.re) : mk<T>(a.im, -a.re); }
+
+// v *= exp(-+ 2 pi i m / R) for compile-time-foldable (R, m)
+template <bool INV, typename T>
+RL_HD cx<T> twiddle_const(cx<T> a, int R, int m) {
+    m %= R;
+    if (m == 0) return a;
+    if (4 * m == R) return rot90<INV>(a);
+    if (2 * m == R) return mk<T>(-a.re, -a.im);
+    if (4 * m == 3 * R) return rot90<!INV>(a);
+    const double ang = 6.283185307179586476925286766559 * (double)m / (double)R;
+    const T c = (T)__builtin_cos(ang);
+    const T s = (T)(INV ? __builtin_sin(ang) : -__builtin_sin(ang));
+    return mk<T>(a.re * c - a.im * s, a.re * s + a.im * c);
+}
+
+template <int R>
+struct radix_split {
+    static constexpr int R1 = (R % 4 == 0 && R > 4) ? 4 : (R % 2 == 0 ? 2 : (R % 3 == 0 ? 3 : 5));
+    static constexpr int R2 = R / R1;
+};
+
+// In-register R-point DFT, forward sign exp(-2 pi i nk/R); INV conjugates it.
+template <int R, bool INV, typename T>
+RL_HD void dft(cx<T>* v) {
+    if constexpr (R == 1) {
+    } else if constexpr (R == 2) {
+        cx<T> a = v[0] + v[1], b = v[0] - v[1];
+        v[0] = a;
+        v[1] = b;
+    } else if constexpr (R == 3) {
+        cx<T> t = v[1] + v[2];
+        cx<T> m = mk<T>(v[0].re - (T)0.5 * t.re, v[0].im - (T)0.5 * t.im);
+        cx<T> d = rot90<INV>(scale(v[1] - v[2], (T)0.86602540378443864676372317075294));
+        v[0] = v[0] + t;
+        v[1] = m + d;
+        v[2] = m - d;
+    } else if constexpr (R == 4) {
+        cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3];
+        cx<T> t3 = rot90<INV>(v[1] - v[3]);
+        v[0] = t0 + t2;
+        v[1] = t1 + t3;
+        v[2] = t0 - t2;
+        v[3] = t1 - t3;
+    } else if constexpr (R == 5) {
+        const T c1 = (T)0.30901699437494742410229341718282, c2 = (T)-0.80901699437494742410229341718282;
+        const T s1 = (T)0.95105651629515357211643933337938, s2 = (T)0.58778525229247312916870595463907;
+        cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
+        cx<T> m1 = mk<T>(v[0].re + c1 * a1.re + c2 * a2.re, v[0].im + c1 * a1.im + c2 * a2.im);
+        cx<T> m2 = mk<T>(v[0].re + c2 * a1.re + c1 * a2.re, v[0].im + c2 * a1.im + c1 * a2.im);
+        cx<T> n1 = rot90<INV>(mk<T>(s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im));
+        cx<T> n2 = rot90<INV>(mk<T>(s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im));
+        v[0] = v[0] + a1 + a2;
+        v[1] = m1 + n1;
+        v[4] = m1 - n1;
+        v[2] = m2 + n2;
+        v[3] = m2 - n2;
+    } else {
+        // Cooley-Tukey R = R1*R2: n = R2*n1 + n2, k = k1 + R1*k2
+        constexpr int R1 = radix_split<R>::R1, R2 = radix_split<R>::R2;
+        cx<T> u[R1];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) u[n1] = v[R2 * n1 + n2];
+            dft<R1, INV>(u);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) v[R2 * k1 + n2] = twiddle_const<INV>(u[k1], R, n2 * k1);
+        }
+        cx<T> y[R];
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            cx<T> z[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) z[n2] = v[R2 * k1 + n2];
+            dft<R2, INV>(z);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) y[k1 + R1 * k2] = z[k2];
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = y[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Transform configuration: length L, T threads per transform, forward radices.
+// The inverse runs the radix list reversed.
+// ---------------------------------------------------------------------------
+template <int L_, int T_, int... Rs>
+struct FftCfg {
+    static constexpr int L = L_;
+    static constexpr int T = T_;
+    static constexpr int NP = sizeof...(Rs);
+    static constexpr int radix(int p) {
+        constexpr int r[NP] = {Rs...};
+        return r[p];
+    }
+    static constexpr int product() {
+        int p = 1;
+        for (int i = 0; i < NP; ++i) p *= radix(i);
+        return p;
+    }
+    static_assert(product() == L_, "radices must multiply to L");
+};
+
+template <class Cfg, bool INV, int P>
+struct PassInfo {
+    static constexpr int NP = Cfg::NP;
+    static constexpr int R = Cfg::radix(INV ? NP - 1 - P : P);
+    static constexpr int ns_() {
+        int n = 1;
+        for (int i = 0; i < P; ++i) n *= Cfg::radix(INV ? NP - 1 - i : i);
+        return n;
+    }
+    static constexpr int NS = ns_();
+    static constexpr int NBF = Cfg::L / R;                    // butterflies in this pass
+    static constexpr int NB = (NBF + Cfg::T - 1) / Cfg::T;    // butterflies per thread
+};
+
+template <class Cfg>
+struct CfgRegs {
+    static constexpr int vmax_() {
+        int m = 0;
+        for (int p = 0; p < Cfg::NP; ++p) {
+            int r = Cfg::radix(p);
+            int nb = (Cfg::L / r + Cfg::T - 1) / Cfg::T;
+            if (nb * r > m) m = nb * r;
+        }
+        return m;
+    }
+    static constexpr int VMAX = vmax_();   // complex registers per thread
+};
+
+// LDS index padding: one extra slot per 8 keeps the stride-R scatter of the
+// radix-8 passes off a single bank group (LDS layout).
+RL_HD int lds_pad(int idx) { return idx + (idx >> 3); }
+template <int L>
+struct LdsLen {
+    static constexpr int value = L + (L >> 3) + 1;
+};
+
+// View of one transform's LDS storage.  CS = element stride (1 for the row
+// kernels' [fft][idx] layout, C for the column kernels' [idx][column] layout).
+template <typename T, int CS>
+struct LdsView {
+    cx<T>* base;
+    RL_HD cx<T>& at(int idx) const { return base[lds_pad(idx) * CS]; }
+};
+
+template <class Cfg, bool INV, int P, typename T>
+RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
+    using PI = PassInfo<Cfg, INV, P>;
+    constexpr int R = PI::R;
+#pragma unroll
+    for (int nb = 0; nb < PI::NB; ++nb) {
+        const int j = t + nb * Cfg::T;
+        if (j < PI::NBF) {
+            if constexpr (PI::NS > 1) {
+                const int base = (j % PI::NS) * (Cfg::L / (PI::NS * R));
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+                    cx<T> w = tw[r * base];
+                    if (INV) w.im = -w.im;
+                    v[nb * R + r] = cmul(v[nb * R + r], w);
+                }
+            }
+            dft<R, INV>(&v[nb * R]);
+        }
+    }
+}
+
+template <class Cfg, bool INV, int P, typename T, int CS>
+RL_HD void pass_store_lds(const cx<T>* v, int t, LdsView<T, CS> lds) {
+    using PI = PassInfo<Cfg, INV, P>;
+    constexpr int R = PI::R;
+#pragma unroll
+    for (int nb = 0; nb < PI::NB; ++nb) {
+        const int j = t + nb * Cfg::T;
+        if (j < PI::NBF) {
+            const int j0 = (j / PI::NS) * (PI::NS * R) + (j % PI::NS);
+#pragma unroll
+            for (int r = 0; r < R; ++r) lds.at(j0 + r * PI::NS) = v[nb * R + r];
+        }
+    }
+}
+
+template <class Cfg, bool INV, int P, typename T, int CS>
+RL_HD void pass_load_lds(cx<T>* v, int t, LdsView<T, CS> lds) {
+    using PI = PassInfo<Cfg, INV, P>;
+    constexpr int R = PI::R;
+#pragma unroll
+    for (int nb = 0; nb < PI::NB; ++nb) {
+        const int j = t + nb * Cfg::T;
+        if (j < PI::NBF) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[nb * R + r] = lds.at(j + r * PI::NBF);
+        }
+    }
+}
+
+// Runs passes P..NP-1.  Pass P takes its input from registers when FROM_REGS,
+// otherwise from LDS (natural order).  The last pass leaves its output in
+// registers: slot nb*R + r  <->  element (t + nb*T) + r*NBF of the last pass.
+// Every LDS scatter is bracketed by barriers (all threads of the workgroup
+// must call this).
+template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, int CS, class Sync>
+RL_HD void run_passes(cx<T>* v, int t, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
+    if constexpr (!FROM_REGS) pass_load_lds<Cfg, INV, P>(v, t, lds);
+    pass_compute<Cfg, INV, P>(v, t, tw);
+    if constexpr (P + 1 < Cfg::NP) {
+        sync();   // everyone has finished reading the previous LDS contents
+        pass_store_lds<Cfg, INV, P>(v, t, lds);
+        sync();
+        run_passes<Cfg, INV, P + 1, false>(v, t, lds, tw, sync);
+    }
+}
+
+}  // namespace rl

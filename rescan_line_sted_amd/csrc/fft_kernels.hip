@@ -1,0 +1,113 @@
+// fft_kernels.hip -- gfx950 kernels for one FFT length (compile with
+// -DRL_CFG_L=<L>).  Column pass (FFT_y * psf_hat -> IFFT_y) and the fused row
+// passes (IFFT_x -> Richardson-Lucy pointwise step -> FFT_x) of the
+// convolution path; bodies in conv_kernels.hpp.
+#include "kernel_table.hpp"
+#include "conv_kernels.hpp"
+#include "fft_configs.hpp"
+
+#ifndef RL_CFG_L
+#error "compile with -DRL_CFG_L=<length>"
+#endif
+
+namespace rl {
+
+using CF = CfgFor<RL_CFG_L>;
+using Cfg = CF::Cfg;
+constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
+#define RL_CAT_(a, b) a##b
+#define RL_CAT(a, b) RL_CAT_(a, b)
+#define RL_TABLE_FN RL_CAT(table_, RL_CFG_L)
+
+struct DevSync {
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
+template <int C, typename T>
+__global__ void __launch_bounds__(Cfg::T* C) k_colconv(const ColParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevSync s;
+    colconv_body<Cfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+}
+
+template <int Q, int MODE, typename T>
+__global__ void __launch_bounds__(Cfg::T* Q) k_rowpass(const RowParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevSync s;
+    rowpass_body<Cfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+}
+
+template <int C, typename T>
+static constexpr size_t lds_bytes() {
+    return (size_t)C * LdsLen<Cfg::L>::value * sizeof(cx<T>);
+}
+
+template <int C, typename T>
+static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
+    const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
+    k_colconv<C, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    return hipGetLastError();
+}
+
+template <int Q, int MODE, typename T>
+static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
+    const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
+    k_rowpass<Q, MODE, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
+    return hipGetLastError();
+}
+
+template <int Q, typename T>
+static hipError_t launch_row_t(int mode, const void* params, unsigned gx, unsigned gy, hipStream_t s) {
+    switch (mode) {
+        case ROW_FWD: return launch_row_m<Q, ROW_FWD, T>(params, gx, gy, s);
+        case ROW_INV: return launch_row_m<Q, ROW_INV, T>(params, gx, gy, s);
+        case ROW_RATIO: return launch_row_m<Q, ROW_RATIO, T>(params, gx, gy, s);
+        case ROW_UPDATE: return launch_row_m<Q, ROW_UPDATE, T>(params, gx, gy, s);
+        case ROW_ADJ: return launch_row_m<Q, ROW_ADJ, T>(params, gx, gy, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigned gy, hipStream_t s) {
+    return dtype == DT_F32 ? launch_col_t<kC32, float>(params, gx, gy, s)
+                           : launch_col_t<kC64, double>(params, gx, gy, s);
+}
+
+static hipError_t launch_row(int dtype, int mode, const void* params, unsigned gx, unsigned gy, hipStream_t s) {
+    return dtype == DT_F32 ? launch_row_t<kQ32, float>(mode, params, gx, gy, s)
+                           : launch_row_t<kQ64, double>(mode, params, gx, gy, s);
+}
+
+template <typename F>
+static hipError_t allow_lds(F* fn, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int Q, typename T>
+static hipError_t prepare_rows() {
+    hipError_t e;
+    const size_t b = lds_bytes<Q, T>();
+    if ((e = allow_lds(k_rowpass<Q, ROW_FWD, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<Q, ROW_INV, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<Q, ROW_RATIO, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<Q, ROW_UPDATE, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<Q, ROW_ADJ, T>, b)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+static hipError_t prepare() {
+    hipError_t e;
+    if ((e = allow_lds(k_colconv<kC32, float>, lds_bytes<kC32, float>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<kC64, double>, lds_bytes<kC64, double>())) != hipSuccess) return e;
+    if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
+    if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+const KernelTable* RL_TABLE_FN() {
+    static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, launch_col, launch_row, prepare};
+    return &t;
+}
+
+}  // namespace rl

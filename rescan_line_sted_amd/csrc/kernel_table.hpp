@@ -1,0 +1,30 @@
+// kernel_table.hpp -- type-erased launch table, one per supported FFT length.
+// Each table is produced by compiling fft_kernels.hip with -DRL_CFG_L=<L>.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace rl {
+
+enum DType { DT_F32 = 0, DT_F64 = 1 };
+
+struct KernelTable {
+    int L;            // transform length
+    int T;            // threads per transform
+    int C[2];         // spectrum columns per workgroup in the column kernel, per dtype
+    int Q[2];         // row pairs per workgroup in the row kernels, per dtype
+    // params: pointer to ColParams<T> / RowParams<T> of the matching dtype
+    hipError_t (*launch_col)(int dtype, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);
+    hipError_t (*launch_row)(int dtype, int mode, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);
+    // one-time attribute setup (dynamic LDS above the default limit)
+    hipError_t (*prepare)(void);
+};
+
+const KernelTable* table_64();
+const KernelTable* table_192();
+const KernelTable* table_256();
+const KernelTable* table_576();
+const KernelTable* table_1152();
+const KernelTable* table_2304();
+
+}  // namespace rl

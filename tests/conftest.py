@@ -27,6 +27,7 @@ def golden():
 
 def max_rel(a, b):
     """Normwise max relative error: max|a-b| / max|b|."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    cplx = np.iscomplexobj(a) or np.iscomplexobj(b)
+    a = np.asarray(a, dtype=np.complex128 if cplx else np.float64)
+    b = np.asarray(b, dtype=np.complex128 if cplx else np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))

@@ -1,0 +1,140 @@
+// Host emulator for the workgroup bodies in rescan_line_sted_amd/csrc/
+// conv_kernels.hpp: runs one OS thread per GPU thread with a pthread barrier
+// standing in for __syncthreads().  TEST INFRASTRUCTURE ONLY -- it exists so
+// the index logic of the HIP kernels (Stockham passes, two-rows-per-transform
+// packing, pad/crop, view loops) can be checked against numpy on a machine
+// without a GPU.  It is built by tests/test_emulated_kernels.py with g++ and
+// is never loaded by the product.
+#include <pthread.h>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../rescan_line_sted_amd/csrc/conv_kernels.hpp"
+#include "../../rescan_line_sted_amd/csrc/fft_configs.hpp"
+
+using namespace rl;
+
+struct EmuSync {
+    pthread_barrier_t* bar;
+    void operator()() const { pthread_barrier_wait(bar); }
+};
+
+template <class Body>
+static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) {
+    std::vector<unsigned char> lds(lds_bytes + 64);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, nthreads);
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            std::memset(lds.data(), 0xff, lds.size());   // poison: NaNs if read before written
+            std::vector<std::thread> th;
+            th.reserve(nthreads);
+            for (int tid = 0; tid < nthreads; ++tid)
+                th.emplace_back([&, tid]() {
+                    EmuSync s{&bar};
+                    body(tid, bx, by, lds.data(), s);
+                });
+            for (auto& t : th) t.join();
+        }
+    pthread_barrier_destroy(&bar);
+}
+
+template <typename T>
+static std::vector<cx<T>> twiddles(int L) {
+    std::vector<cx<T>> tw(L);
+    for (int m = 0; m < L; ++m) {
+        long double a = -2.0L * 3.14159265358979323846264338327950288L * m / L;
+        tw[m] = mk<T>((T)cosl(a), (T)sinl(a));
+    }
+    return tw;
+}
+
+template <int L, typename T>
+static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitch, int V, int frames,
+                 int in_sb, int in_sv) {
+    using CF = CfgFor<L>;
+    using Cfg = typename CF::Cfg;
+    constexpr int C = sizeof(T) == 4 ? CF::C32 : CF::C64;
+    auto tw = twiddles<T>(L);
+    ColParams<T> p;
+    p.in = reinterpret_cast<const cx<T>*>(in);
+    p.out = reinterpret_cast<cx<T>*>(out);
+    p.psf_hat = reinterpret_cast<const cx<T>*>(psf_hat);
+    p.tw = tw.data();
+    p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
+    run_grid((kx + C - 1) / C, frames * V, Cfg::T * C, (size_t)C * LdsLen<L>::value * sizeof(cx<T>),
+             [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                 colconv_body<Cfg, C, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+             });
+    return 0;
+}
+
+template <int L, int MODE, typename T>
+static int row_m(const RowParams<T>& p, int gy) {
+    using CF = CfgFor<L>;
+    using Cfg = typename CF::Cfg;
+    constexpr int Q = sizeof(T) == 4 ? CF::Q32 : CF::Q64;
+    const int pairs = (p.ny + 1) / 2;
+    run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsLen<L>::value * sizeof(cx<T>),
+             [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                 rowpass_body<Cfg, Q, MODE, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+             });
+    return 0;
+}
+
+template <int L, typename T>
+static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, const T* scale,
+                 int ny, int nx, int pitch, int V, int gy) {
+    auto tw = twiddles<T>(L);
+    RowParams<T> p;
+    p.spec_in = reinterpret_cast<const cx<T>*>(spec_in);
+    p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
+    p.src = src; p.dst = dst; p.norm = norm; p.scale = scale; p.tw = tw.data();
+    p.ny = ny; p.nx = nx; p.pitch = pitch; p.V = V;
+    switch (mode) {
+        case ROW_FWD: return row_m<L, ROW_FWD, T>(p, gy);
+        case ROW_INV: return row_m<L, ROW_INV, T>(p, gy);
+        case ROW_RATIO: return row_m<L, ROW_RATIO, T>(p, gy);
+        case ROW_UPDATE: return row_m<L, ROW_UPDATE, T>(p, gy);
+        case ROW_ADJ: return row_m<L, ROW_ADJ, T>(p, gy);
+    }
+    return -1;
+}
+
+#define DISPATCH_L(L, call)                         \
+    switch (L) {                                    \
+        case 64: { constexpr int LL = 64; return call; }     \
+        case 192: { constexpr int LL = 192; return call; }   \
+        case 256: { constexpr int LL = 256; return call; }   \
+        case 576: { constexpr int LL = 576; return call; }   \
+        default: return -2;                         \
+    }
+
+extern "C" {
+
+int emu_geometry(int L, int* T, int* C, int* Q) {
+#define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return 0;
+    switch (L) { GEO(64) GEO(192) GEO(256) GEO(576) GEO(1152) GEO(2304) }
+    return -2;
+}
+
+int emu_col_f64(int L, const double* in, double* out, const double* psf_hat, int ny, int kx, int pitch, int V,
+                int frames, int in_sb, int in_sv) {
+    DISPATCH_L(L, (col_t<LL, double>(in, out, psf_hat, ny, kx, pitch, V, frames, in_sb, in_sv)))
+}
+int emu_col_f32(int L, const float* in, float* out, const float* psf_hat, int ny, int kx, int pitch, int V,
+                int frames, int in_sb, int in_sv) {
+    DISPATCH_L(L, (col_t<LL, float>(in, out, psf_hat, ny, kx, pitch, V, frames, in_sb, in_sv)))
+}
+int emu_row_f64(int L, int mode, const double* spec_in, double* spec_out, const double* src, double* dst,
+                const double* norm, const double* scale, int ny, int nx, int pitch, int V, int gy) {
+    DISPATCH_L(L, (row_t<LL, double>(mode, spec_in, spec_out, src, dst, norm, scale, ny, nx, pitch, V, gy)))
+}
+int emu_row_f32(int L, int mode, const float* spec_in, float* spec_out, const float* src, float* dst,
+                const float* norm, const float* scale, int ny, int nx, int pitch, int V, int gy) {
+    DISPATCH_L(L, (row_t<LL, float>(mode, spec_in, spec_out, src, dst, norm, scale, ny, nx, pitch, V, gy)))
+}
+}

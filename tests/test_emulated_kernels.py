@@ -1,0 +1,205 @@
+"""Index-logic check of the HIP workgroup bodies without a GPU.
+
+tests/emu/emu.cpp compiles the very same templates the HIP kernels are made of
+(rescan_line_sted_amd/csrc/conv_kernels.hpp) for the host and runs them with
+one OS thread per GPU thread.  Here the emulated kernels are chained exactly as
+the device plan chains them and compared with the CPU oracle.  CPU only.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import line_sted_oracle as orc
+from conftest import max_rel, ROOT
+
+EMU_DIR = os.path.join(ROOT, 'tests', 'emu')
+ROW_FWD, ROW_INV, ROW_RATIO, ROW_UPDATE, ROW_ADJ = range(5)
+
+
+@pytest.fixture(scope='module')
+def emu():
+    so = os.path.join(EMU_DIR, 'libemu.so')
+    src = os.path.join(EMU_DIR, 'emu.cpp')
+    deps = [src] + [os.path.join(ROOT, 'rescan_line_sted_amd', 'csrc', f)
+                    for f in ('conv_kernels.hpp', 'fft_core.hpp', 'fft_configs.hpp')]
+    if (not os.path.exists(so) or
+            os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps)):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared',
+                               '-pthread', src, '-o', so])
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class EmuPlan:
+    """Mirrors the device plan: buffers + kernel sequence, f64 or f32."""
+
+    def __init__(self, lib, psfs, ny, nx, Ly, Lx, dtype=np.float64):
+        self.lib, self.ny, self.nx, self.Ly, self.Lx = lib, ny, nx, Ly, Lx
+        self.rt = np.dtype(dtype)
+        self.ct = np.complex128 if self.rt == np.float64 else np.complex64
+        self.sfx = 'f64' if self.rt == np.float64 else 'f32'
+        self.V = len(psfs)
+        self.kx = Lx // 2 + 1
+        self.pitch = (self.kx + 7) // 8 * 8
+        ph = np.zeros((self.V, Ly, self.pitch), dtype=self.ct)
+        for v, p in enumerate(psfs):
+            Py, Px = p.shape[1:]
+            cy, cx = (Py - 1) // 2, (Px - 1) // 2
+            assert Ly >= ny + max(cy, Py - 1 - cy) and Lx >= nx + max(cx, Px - 1 - cx)
+            w = np.zeros((Ly, Lx))
+            yy = (np.arange(Py) - cy) % Ly
+            xx = (np.arange(Px) - cx) % Lx
+            w[np.ix_(yy, xx)] = p[0]
+            ph[v, :, :self.kx] = np.fft.rfft2(w) / (Ly * Lx)
+        self.psf_hat = ph
+
+    def row(self, mode, gy, spec_in=None, spec_out=None, src=None, dst=None,
+            norm=None, scale=None):
+        f = getattr(self.lib, 'emu_row_' + self.sfx)
+        rc = f(self.Lx, mode, _p(spec_in) if spec_in is not None else None,
+               _p(spec_out) if spec_out is not None else None,
+               _p(src) if src is not None else None,
+               _p(dst) if dst is not None else None,
+               _p(norm) if norm is not None else None,
+               _p(scale) if scale is not None else None,
+               self.ny, self.nx, self.pitch, self.V, gy)
+        assert rc == 0
+
+    def col(self, spec_in, spec_out, frames, h_mode):
+        f = getattr(self.lib, 'emu_col_' + self.sfx)
+        rc = f(self.Ly, _p(spec_in), _p(spec_out), _p(self.psf_hat), self.ny,
+               self.kx, self.pitch, self.V, frames,
+               1 if h_mode else self.V, 0 if h_mode else 1)
+        assert rc == 0
+
+    def spec(self, n):
+        # NaN-poisoned so that any read of a never-written element shows up
+        return np.full((n, self.ny, self.pitch), np.nan + 1j * np.nan, dtype=self.ct)
+
+    def H(self, x):
+        B = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=self.rt)
+        sa, sb = self.spec(B), self.spec(B * self.V)
+        self.row(ROW_FWD, B, spec_out=sa, src=x)
+        self.col(sa, sb, B, True)
+        out = np.full((B * self.V, self.ny, self.nx), np.nan, dtype=self.rt)
+        self.row(ROW_INV, B * self.V, spec_in=sb, dst=out)
+        return out.reshape(B, self.V, self.ny, self.nx), sa
+
+    def normalization(self):
+        ones = np.ones((1, self.ny, self.nx), dtype=self.rt)
+        sa, sb = self.spec(1), self.spec(self.V)
+        self.row(ROW_FWD, 1, spec_out=sa, src=ones)
+        self.col(sa, sb, 1, True)
+        norm = np.full((self.ny, self.nx), np.nan, dtype=self.rt)
+        self.row(ROW_ADJ, 1, spec_in=sb, dst=norm)
+        return norm
+
+    def rl(self, meas, K):
+        B = meas.shape[0]
+        meas = np.ascontiguousarray(meas.reshape(B * self.V, self.ny, self.nx), dtype=self.rt)
+        norm = self.normalization()
+        est = np.ones((B, self.ny, self.nx), dtype=self.rt)
+        sa, sb = self.spec(B), self.spec(B * self.V)
+        self.row(ROW_FWD, B, spec_out=sa, src=est)
+        for _ in range(K):
+            self.col(sa, sb, B, True)
+            self.row(ROW_RATIO, B * self.V, spec_in=sb, spec_out=sb, src=meas)
+            self.col(sb, sb, B, False)
+            self.row(ROW_UPDATE, B, spec_in=sb, spec_out=sa, dst=est, norm=norm)
+        return est, norm
+
+
+def test_row_forward_is_rfft_of_padded_rows(emu):
+    rng = np.random.default_rng(1)
+    for (ny, nx, L) in ((6, 40, 64), (5, 33, 64), (4, 130, 192)):
+        pl = EmuPlan(emu, [np.ones((1, 1, 1))], ny, nx, 64, L)
+        x = rng.random((2, ny, nx))
+        sc = np.array([2.0, 0.5])
+        out = pl.spec(2)
+        pl.row(ROW_FWD, 2, spec_out=out, src=x, scale=sc)
+        ref = np.fft.rfft(x * sc[:, None, None], n=L, axis=2)
+        assert max_rel(out[:, :, :pl.kx], ref) < 1e-14
+
+
+def test_column_pass_is_circular_convolution_along_y(emu):
+    rng = np.random.default_rng(2)
+    for Ly, ny in ((64, 37), (192, 130), (256, 161)):
+        pl = EmuPlan(emu, [rng.random((1, 5, 3)), rng.random((1, 4, 6))], ny, 8, Ly, 64)
+        B = 2
+        sin = pl.spec(B)
+        sin[:, :, :pl.kx] = rng.random((B, ny, pl.kx)) + 1j * rng.random((B, ny, pl.kx))
+        sout = pl.spec(B * pl.V)
+        pl.col(sin, sout, B, True)
+        for b in range(B):
+            for v in range(pl.V):
+                pad = np.zeros((Ly, pl.kx), dtype=complex)
+                pad[:ny] = sin[b, :, :pl.kx]
+                ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat[v, :, :pl.kx], axis=0)[:ny] * Ly
+                assert max_rel(sout[b * pl.V + v, :, :pl.kx], ref) < 1e-13
+        # H_t indexing, in place
+        s2 = pl.spec(B * pl.V)
+        s2[:, :, :pl.kx] = rng.random((B * pl.V, ny, pl.kx)) + 0j
+        keep = s2.copy()
+        pl.col(s2, s2, B, False)
+        for i in range(B * pl.V):
+            pad = np.zeros((Ly, pl.kx), dtype=complex)
+            pad[:ny] = keep[i, :, :pl.kx]
+            ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat[i % pl.V, :, :pl.kx], axis=0)[:ny] * Ly
+            assert max_rel(s2[i, :, :pl.kx], ref) < 1e-13
+
+
+@pytest.mark.parametrize('ny,nx,Ly,Lx,pshapes', [
+    (40, 48, 64, 64, [(1, 9, 11)]),
+    (33, 31, 64, 64, [(1, 7, 7), (1, 8, 10), (1, 1, 7)]),    # odd sizes, even PSF, 3 views
+    (128, 128, 192, 192, [(1, 107, 107)]),
+])
+def test_forward_model_matches_oracle(emu, ny, nx, Ly, Lx, pshapes):
+    rng = np.random.default_rng(3)
+    psfs = [rng.random(s) for s in pshapes]
+    pl = EmuPlan(emu, psfs, ny, nx, Ly, Lx)
+    x = rng.random((2, ny, nx))
+    got, _ = pl.H(x)
+    d = orc.Deconvolver(psfs)
+    ref = d.H(x)
+    for v in range(len(psfs)):
+        assert max_rel(got[:, v], ref[v]) < 1e-13
+    norm = pl.normalization()
+    assert max_rel(norm, d.H_t([np.ones((1, ny, nx))] * len(psfs), normalize=False)[0]) < 1e-13
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-11), (np.float32, 2e-5)])
+def test_richardson_lucy_matches_oracle(emu, dtype, tol):
+    rng = np.random.default_rng(4)
+    ny, nx = 33, 31
+    psfs = [rng.random((1, 7, 7)), rng.random((1, 5, 9))]
+    obj = rng.random((1, ny, nx)) * 50
+    d = orc.Deconvolver(psfs)
+    d.create_data_from_object(obj, random_seed=0)
+    for _ in range(4):
+        d.iterate()
+    pl = EmuPlan(emu, psfs, ny, nx, 64, 64, dtype)
+    meas = np.array(d.noisy_measurement)[None, :, 0]       # (B=1, V, ny, nx)
+    est, _ = pl.rl(meas, 4)
+    assert max_rel(est[0], d.estimate[0]) < tol
+
+
+def test_golden_rl_through_emulated_kernels(emu, golden):
+    """rings 128x128, the real 107x107 fig-2 point PSF, 2 RL iterations (f64)."""
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    psf = [psfs['1p5x_lr/point_sted_psf'][0]]
+    pl = EmuPlan(emu, psf, 128, 128, 192, 192)
+    obj = objs['rings'].astype(np.float64)
+    obj = obj * (5e10 / obj.sum())
+    got, _ = pl.H(obj)
+    assert max_rel(got[0, 0], g['rings_point_1p5x/noiseless'][0, 0]) < 1e-13
+    est, norm = pl.rl(g['rings_point_1p5x/noisy'][None, :, 0], 2)
+    assert max_rel(norm, g['rings_point_1p5x/norm'][0]) < 1e-13
+    ref = g['rings_point_1p5x/estimate_2'][0]
+    assert (np.abs(est[0] - ref) / np.abs(ref)).max() < 1e-9
