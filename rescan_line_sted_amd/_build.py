@@ -1,0 +1,80 @@
+"""Build librlsted.so (hipcc, gfx950) in-tree.
+
+    python -m rescan_line_sted_amd._build [--force]
+
+Objects go to build/ (git-ignored), the library to rescan_line_sted_amd/_lib/.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(ROOT, 'build', 'obj')
+LIBDIR = os.path.join(HERE, '_lib')
+LIB = os.path.join(LIBDIR, 'librlsted.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+FFT_LENGTHS = (64, 192, 256, 576, 1152, 2304)
+COMMON = ['-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include')]
+DEVICE = ['--offload-arch=' + ARCH, '-munsafe-fp-atomics']
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h'))] + \
+           [os.path.join(ROOT, 'include', 'rlsted.h')]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('build failed: %s\n%s' % (' '.join(cmd), r.stdout))
+    return r.stdout
+
+
+def jobs():
+    out = []
+    for L in FFT_LENGTHS:
+        out.append((os.path.join(OBJ, 'fft_%d.o' % L), os.path.join(CSRC, 'fft_kernels.hip'),
+                    DEVICE + ['-DRL_CFG_L=%d' % L]))
+    out.append((os.path.join(OBJ, 'aux_kernels.o'), os.path.join(CSRC, 'aux_kernels.hip'), DEVICE))
+    out.append((os.path.join(OBJ, 'psf_kernels.o'), os.path.join(CSRC, 'psf_kernels.hip'), DEVICE))
+    out.append((os.path.join(OBJ, 'rlsted.o'), os.path.join(CSRC, 'rlsted.cpp'), ['-x', 'hip'] + DEVICE))
+    out.append((os.path.join(OBJ, 'psf_api.o'), os.path.join(CSRC, 'psf_api.cpp'), ['-x', 'hip'] + DEVICE))
+    return [j for j in out if os.path.exists(j[1])]
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = _headers()
+    todo = [(o, s, f) for o, s, f in jobs() if force or _stale(o, [s] + hdrs)]
+
+    def compile_one(job):
+        o, s, f = job
+        _run([HIPCC] + COMMON + f + ['-c', s, '-o', o])
+        return o
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            for o in ex.map(compile_one, todo):
+                if verbose:
+                    print('compiled', os.path.relpath(o, ROOT))
+    objs = [o for o, _, _ in jobs()]
+    if force or todo or _stale(LIB, objs):
+        _run([HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH] + objs + ['-o', LIB])
+        if verbose:
+            print('linked', os.path.relpath(LIB, ROOT))
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

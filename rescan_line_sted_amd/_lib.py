@@ -1,0 +1,205 @@
+"""ctypes binding of librlsted.so (C ABI: include/rlsted.h).
+
+The library is the product: if it is missing or fails to load, importing this
+module raises -- there is no CPU fallback for the device path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'librlsted.so')
+
+RL_F32, RL_F64 = 0, 1
+RNG_NONE, RNG_PHILOX = 0, 1
+DTYPES = {'f32': RL_F32, 'float32': RL_F32, 'f64': RL_F64, 'float64': RL_F64}
+
+# name -> (restype, argtypes); exactly the symbols include/rlsted.h declares
+_c = ctypes
+_vp, _i, _dp = _c.c_void_p, _c.c_int, _c.POINTER(_c.c_double)
+PROTOTYPES = {
+    'rl_last_error': (_c.c_char_p, []),
+    'rl_version': (_i, []),
+    'rl_device_count': (_i, [_c.POINTER(_i)]),
+    'rl_ctx_create': (_i, [_i, _c.POINTER(_vp)]),
+    'rl_ctx_destroy': (_i, [_vp]),
+    'rl_ctx_synchronize': (_i, [_vp]),
+    'rl_fft_length_for': (_i, [_i]),
+    'rl_deconv_create': (_i, [_vp, _dp, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
+    'rl_deconv_destroy': (_i, [_vp]),
+    'rl_deconv_info': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_c.c_size_t)]),
+    'rl_deconv_set_object': (_i, [_vp, _dp, _dp]),
+    'rl_deconv_simulate': (_i, [_vp, _i, _c.c_uint64]),
+    'rl_deconv_set_measurement': (_i, [_vp, _dp]),
+    'rl_deconv_iterate': (_i, [_vp, _i]),
+    'rl_deconv_reset_estimate': (_i, [_vp]),
+    'rl_deconv_get_object': (_i, [_vp, _dp]),
+    'rl_deconv_get_noiseless': (_i, [_vp, _dp]),
+    'rl_deconv_get_measurement': (_i, [_vp, _dp]),
+    'rl_deconv_get_estimate': (_i, [_vp, _dp]),
+    'rl_deconv_get_normalization': (_i, [_vp, _dp]),
+    'rl_forward': (_i, [_vp, _dp, _dp]),
+    'rl_adjoint': (_i, [_vp, _dp, _dp, _i]),
+    'rl_deconv_last_ms': (_i, [_vp, _dp, _dp]),
+    'rl_deconv_bench_cycles': (_i, [_vp, _i, _i, _i, _c.c_uint64, _dp]),
+    'rl_deconv_time_kernels': (_i, [_vp, _i, _dp]),
+}
+
+
+class RlstedError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'librlsted.so is not built (%s). Run `python -m rescan_line_sted_amd._build` '
+            '(needs hipcc); there is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise RlstedError('librlsted error %d: %s' % (rc, lib.rl_last_error().decode()))
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def device_count():
+    n = _i(0)
+    rc = lib.rl_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One per GPU (rl_ctx)."""
+    _cache = {}
+
+    def __init__(self, device=0):
+        self.handle = _vp()
+        check(lib.rl_ctx_create(device, ctypes.byref(self.handle)))
+        self.device = device
+
+    @classmethod
+    def get(cls, device=0):
+        if device not in cls._cache:
+            cls._cache[device] = Context(device)
+        return cls._cache[device]
+
+    def synchronize(self):
+        check(lib.rl_ctx_synchronize(self.handle))
+
+
+class DeconvPlan:
+    """rl_deconv: `batch` frames sharing one PSF set and one image shape."""
+
+    def __init__(self, psfs, batch, ny, nx, dtype='f32', device=0):
+        psfs = [as_f64(p) for p in psfs]
+        for p in psfs:
+            if p.ndim != 3 or p.shape[0] != 1 or p.shape != psfs[0].shape:
+                raise ValueError('PSFs must all have the same shape (1, py, px); got %s'
+                                 % [q.shape for q in psfs])
+        self.ctx = Context.get(device)
+        self.psf_stack = as_f64(np.concatenate(psfs, axis=0))
+        self.V, self.py, self.px = self.psf_stack.shape
+        self.B, self.ny, self.nx = int(batch), int(ny), int(nx)
+        self.dtype = dtype
+        self.handle = _vp()
+        check(lib.rl_deconv_create(self.ctx.handle, ptr(self.psf_stack), self.V, self.py, self.px,
+                                   self.B, self.ny, self.nx, DTYPES[dtype], ctypes.byref(self.handle)))
+
+    def __del__(self):
+        h = getattr(self, 'handle', None)
+        if h:
+            lib.rl_deconv_destroy(h)
+            self.handle = None
+
+    def info(self):
+        ly, lx, pitch, nbytes = _i(), _i(), _i(), _c.c_size_t()
+        check(lib.rl_deconv_info(self.handle, ctypes.byref(ly), ctypes.byref(lx), ctypes.byref(pitch),
+                                 ctypes.byref(nbytes)))
+        return {'ly': ly.value, 'lx': lx.value, 'pitch': pitch.value, 'device_bytes': nbytes.value}
+
+    def set_object(self, obj, total_brightness=None):
+        obj = as_f64(obj).reshape(self.B, self.ny, self.nx)
+        tb = None
+        if total_brightness is not None:
+            tb = as_f64(np.broadcast_to(np.asarray(total_brightness, dtype=np.float64), (self.B,)))
+        check(lib.rl_deconv_set_object(self.handle, ptr(obj), ptr(tb) if tb is not None else None))
+
+    def simulate(self, seed=0, rng=RNG_PHILOX):
+        check(lib.rl_deconv_simulate(self.handle, rng, _c.c_uint64(seed)))
+
+    def set_measurement(self, noisy):
+        noisy = as_f64(noisy).reshape(self.B, self.V, self.ny, self.nx)
+        check(lib.rl_deconv_set_measurement(self.handle, ptr(noisy)))
+
+    def iterate(self, k=1):
+        check(lib.rl_deconv_iterate(self.handle, int(k)))
+
+    def reset_estimate(self):
+        check(lib.rl_deconv_reset_estimate(self.handle))
+
+    def _get(self, fn, shape):
+        out = np.empty(shape, dtype=np.float64)
+        check(fn(self.handle, ptr(out)))
+        return out
+
+    def object(self):
+        return self._get(lib.rl_deconv_get_object, (self.B, self.ny, self.nx))
+
+    def noiseless(self):
+        return self._get(lib.rl_deconv_get_noiseless, (self.B, self.V, self.ny, self.nx))
+
+    def measurement(self):
+        return self._get(lib.rl_deconv_get_measurement, (self.B, self.V, self.ny, self.nx))
+
+    def estimate(self):
+        return self._get(lib.rl_deconv_get_estimate, (self.B, self.ny, self.nx))
+
+    def normalization(self):
+        return self._get(lib.rl_deconv_get_normalization, (self.ny, self.nx))
+
+    def forward(self, x):
+        x = as_f64(x).reshape(self.B, self.ny, self.nx)
+        out = np.empty((self.B, self.V, self.ny, self.nx), dtype=np.float64)
+        check(lib.rl_forward(self.handle, ptr(x), ptr(out)))
+        return out
+
+    def adjoint(self, y, normalize=True):
+        y = as_f64(y).reshape(self.B, self.V, self.ny, self.nx)
+        out = np.empty((self.B, self.ny, self.nx), dtype=np.float64)
+        check(lib.rl_adjoint(self.handle, ptr(y), ptr(out), 1 if normalize else 0))
+        return out
+
+    def last_ms(self):
+        a, b = _c.c_double(), _c.c_double()
+        check(lib.rl_deconv_last_ms(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return {'iterate_ms': a.value, 'simulate_ms': b.value}
+
+    def bench_cycles(self, k, reps, rng=RNG_PHILOX, seed=0):
+        ms = _c.c_double()
+        check(lib.rl_deconv_bench_cycles(self.handle, int(k), int(reps), rng, _c.c_uint64(seed), ctypes.byref(ms)))
+        return ms.value
+
+    KERNEL_NAMES = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'poisson')
+
+    def time_kernels(self, reps=20):
+        out = np.zeros(6, dtype=np.float64)
+        check(lib.rl_deconv_time_kernels(self.handle, int(reps), ptr(out)))
+        return dict(zip(self.KERNEL_NAMES, out.tolist()))
+

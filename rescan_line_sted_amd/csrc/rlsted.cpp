@@ -1,0 +1,578 @@
+// rlsted.cpp -- C ABI (include/rlsted.h) over the gfx950 kernels.
+// Host orchestration only: buffer ownership, kernel sequencing on one HIP
+// stream per context, host<->device staging.  No arithmetic of the hot path
+// runs on the host.
+#include "../../include/rlsted.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.hpp"
+#include "conv_kernels.hpp"
+#include "kernel_table.hpp"
+
+using namespace rl;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+#define RL_TRY(expr)            \
+    do {                        \
+        int r_ = (expr);        \
+        if (r_ != RL_OK) return r_; \
+    } while (0)
+
+const KernelTable* table_for(int L) {
+    switch (L) {
+        case 64: return table_64();
+        case 192: return table_192();
+        case 256: return table_256();
+        case 576: return table_576();
+        case 1152: return table_1152();
+        case 2304: return table_2304();
+    }
+    return nullptr;
+}
+const int kLengths[] = {64, 192, 256, 576, 1152, 2304};
+
+size_t esize(int dtype) { return dtype == RL_F32 ? 4 : 8; }
+
+struct Twiddles {
+    void* t = nullptr;     // complex of plan dtype
+    void* d = nullptr;     // complex128 (PSF spectrum)
+};
+
+}  // namespace
+
+struct rl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::pair<int, int>, void*> tw;   // (L, dtype) -> device table
+    std::map<int, bool> prepared;
+
+    int twiddles(int L, int dtype, void** out) {
+        auto key = std::make_pair(L, dtype);
+        auto it = tw.find(key);
+        if (it != tw.end()) {
+            *out = it->second;
+            return RL_OK;
+        }
+        std::vector<double> h(2 * (size_t)L);
+        for (int m = 0; m < L; ++m) {
+            // exact octant symmetry is not needed: long double cos/sin of the reduced angle
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)L;
+            h[2 * m] = (double)cosl(a);
+            h[2 * m + 1] = (double)sinl(a);
+        }
+        void* dev = nullptr;
+        if (dtype == RL_F64) {
+            HIP_TRY(hipMalloc(&dev, sizeof(double) * 2 * L));
+            HIP_TRY(hipMemcpy(dev, h.data(), sizeof(double) * 2 * L, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> f(h.begin(), h.end());
+            HIP_TRY(hipMalloc(&dev, sizeof(float) * 2 * L));
+            HIP_TRY(hipMemcpy(dev, f.data(), sizeof(float) * 2 * L, hipMemcpyHostToDevice));
+        }
+        tw[key] = dev;
+        *out = dev;
+        return RL_OK;
+    }
+
+    int prepare(const KernelTable* t) {
+        if (prepared[t->L]) return RL_OK;
+        HIP_TRY(t->prepare());
+        prepared[t->L] = true;
+        return RL_OK;
+    }
+};
+
+struct rl_deconv {
+    rl_ctx* ctx = nullptr;
+    int V = 0, py = 0, px = 0, B = 0, ny = 0, nx = 0, dtype = RL_F32;
+    int ly = 0, lx = 0, kx = 0, pitch = 0;
+    const KernelTable *ty = nullptr, *tx = nullptr;
+    void *twy = nullptr, *twx = nullptr;
+    // device buffers (element type = dtype)
+    void* psf_hat = nullptr;   // [V][ly][pitch] complex
+    void* spec_a = nullptr;    // [B][ny][pitch] complex
+    void* spec_b = nullptr;    // [B*V][ny][pitch] complex
+    void* obj = nullptr;       // [B][ny][nx]
+    void* noiseless = nullptr; // [B*V][ny][nx]
+    void* meas = nullptr;      // [B*V][ny][nx]
+    void* est = nullptr;       // [B][ny][nx]
+    void* norm = nullptr;      // [ny][nx]
+    void* scratch = nullptr;   // [B*V][ny][nx] staging for rl_forward / rl_adjoint
+    size_t bytes = 0;
+    bool have_obj = false, have_meas = false;
+    bool est_ready = false;    // est holds a valid estimate
+    bool spec_valid = false;   // spec_a holds rowFFT(est)
+    long iterations = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_iter_ms = 0, last_sim_ms = 0;
+    std::vector<double> stage;   // host staging
+
+    size_t n_img() const { return (size_t)ny * nx; }
+    size_t n_spec() const { return (size_t)ny * pitch; }
+
+    template <typename T>
+    ColParams<T> colp(const void* in, void* out, bool h_mode) const {
+        ColParams<T> p;
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.psf_hat = (const cx<T>*)psf_hat;
+        p.tw = (const cx<T>*)twy;
+        p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V;
+        p.in_sb = h_mode ? 1 : V;
+        p.in_sv = h_mode ? 0 : 1;
+        return p;
+    }
+    int col(const void* in, void* out, int frames, bool h_mode) {
+        const int C = ty->C[dtype];
+        const unsigned gx = (unsigned)((kx + C - 1) / C), gy = (unsigned)(frames * V);
+        if (dtype == RL_F32) {
+            auto p = colp<float>(in, out, h_mode);
+            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
+        } else {
+            auto p = colp<double>(in, out, h_mode);
+            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
+        }
+        return RL_OK;
+    }
+    template <typename T>
+    int row_t(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
+              const void* scale) {
+        RowParams<T> p;
+        p.spec_in = (const cx<T>*)spec_in;
+        p.spec_out = (cx<T>*)spec_out;
+        p.src = (const T*)src;
+        p.dst = (T*)dst;
+        p.norm = (const T*)nrm;
+        p.scale = (const T*)scale;
+        p.tw = (const cx<T>*)twx;
+        p.ny = ny; p.nx = nx; p.pitch = pitch; p.V = V;
+        const int Q = tx->Q[dtype];
+        const unsigned pairs = (unsigned)((ny + 1) / 2);
+        HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
+        return RL_OK;
+    }
+    int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
+            const void* scale = nullptr) {
+        return dtype == RL_F32 ? row_t<float>(mode, gy, spec_in, spec_out, src, dst, nrm, scale)
+                               : row_t<double>(mode, gy, spec_in, spec_out, src, dst, nrm, scale);
+    }
+
+    // host double [n] -> device dtype
+    int upload(const double* src, void* dst, size_t n) {
+        if (dtype == RL_F64) {
+            HIP_TRY(hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            std::vector<float> f(n);
+            for (size_t i = 0; i < n; ++i) f[i] = (float)src[i];
+            HIP_TRY(hipMemcpyAsync(dst, f.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return RL_OK;
+    }
+    int download(const void* src, double* dst, size_t n) {
+        if (dtype == RL_F64) {
+            HIP_TRY(hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            std::vector<float> f(n);
+            HIP_TRY(hipMemcpyAsync(f.data(), src, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            for (size_t i = 0; i < n; ++i) dst[i] = (double)f[i];
+        }
+        return RL_OK;
+    }
+
+    // noiseless = H(obj) on the device
+    int forward_object() {
+        RL_TRY(row(ROW_FWD, (unsigned)B, nullptr, spec_a, obj, nullptr, nullptr));
+        RL_TRY(col(spec_a, spec_b, B, true));
+        RL_TRY(row(ROW_INV, (unsigned)(B * V), spec_b, nullptr, nullptr, noiseless, nullptr));
+        return RL_OK;
+    }
+    int start_estimate() {
+        HIP_TRY(aux_fill(dtype, est, (size_t)B * n_img(), 1.0, ctx->stream));
+        RL_TRY(row(ROW_FWD, (unsigned)B, nullptr, spec_a, est, nullptr, nullptr));
+        est_ready = true;
+        spec_valid = true;
+        iterations = 0;
+        return RL_OK;
+    }
+    int iterate_once() {
+        RL_TRY(col(spec_a, spec_b, B, true));                                              // H(est), column part
+        RL_TRY(row(ROW_RATIO, (unsigned)(B * V), spec_b, spec_b, meas, nullptr, nullptr)); // meas / H(est)
+        RL_TRY(col(spec_b, spec_b, B, false));                                             // H_t, column part
+        RL_TRY(row(ROW_UPDATE, (unsigned)B, spec_b, spec_a, nullptr, est, norm));          // est *= H_t / norm
+        ++iterations;
+        return RL_OK;
+    }
+};
+
+extern "C" {
+
+const char* rl_last_error(void) { return g_err.c_str(); }
+int rl_version(void) { return 100; }
+
+int rl_device_count(int* count) {
+    if (!count) return fail(RL_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(RL_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return RL_OK;
+}
+
+int rl_fft_length_for(int n) {
+    for (int L : kLengths)
+        if (L >= n) return L;
+    return 0;
+}
+
+int rl_ctx_create(int device, rl_ctx** out) {
+    if (!out) return fail(RL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RL_ERR_INVALID, "no such device");
+    HIP_TRY(hipSetDevice(device));
+    rl_ctx* c = new rl_ctx;
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(RL_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return RL_OK;
+}
+
+int rl_ctx_destroy(rl_ctx* c) {
+    if (!c) return RL_OK;
+    hipSetDevice(c->device);
+    for (auto& kv : c->tw) hipFree(kv.second);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return RL_OK;
+}
+
+int rl_ctx_synchronize(rl_ctx* c) {
+    if (!c) return fail(RL_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RL_OK;
+}
+
+int rl_deconv_destroy(rl_deconv* h) {
+    if (!h) return RL_OK;
+    hipSetDevice(h->ctx->device);
+    void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    delete h;
+    return RL_OK;
+}
+
+static int deconv_build(rl_deconv* h, const double* psfs) {
+    rl_ctx* ctx = h->ctx;
+    const int cy_lo = (h->py - 1) / 2, cy_hi = h->py - 1 - cy_lo;
+    const int cx_lo = (h->px - 1) / 2, cx_hi = h->px - 1 - cx_lo;
+    // wrap-free sizes: L >= n + max(offset below, offset above the PSF centre)
+    h->ly = rl_fft_length_for(h->ny + (cy_lo > cy_hi ? cy_lo : cy_hi));
+    h->lx = rl_fft_length_for(h->nx + (cx_lo > cx_hi ? cx_lo : cx_hi));
+    if (!h->ly || !h->lx)
+        return fail(RL_ERR_UNSUPPORTED, "image + PSF half width exceeds the largest built transform length (2304)");
+    h->ty = table_for(h->ly);
+    h->tx = table_for(h->lx);
+    h->kx = h->lx / 2 + 1;
+    h->pitch = (h->kx + 7) / 8 * 8;
+    RL_TRY(ctx->prepare(h->ty));
+    RL_TRY(ctx->prepare(h->tx));
+    RL_TRY(ctx->twiddles(h->ly, h->dtype, &h->twy));
+    RL_TRY(ctx->twiddles(h->lx, h->dtype, &h->twx));
+    const size_t es = esize(h->dtype), B = (size_t)h->B, V = (size_t)h->V;
+    struct Req { void** p; size_t n; };
+    const Req reqs[] = {
+        {&h->psf_hat, V * h->ly * h->pitch * 2 * es}, {&h->spec_a, B * h->n_spec() * 2 * es},
+        {&h->spec_b, B * V * h->n_spec() * 2 * es},   {&h->obj, B * h->n_img() * es},
+        {&h->noiseless, B * V * h->n_img() * es},     {&h->meas, B * V * h->n_img() * es},
+        {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
+        {&h->scratch, B * V * h->n_img() * es}};
+    for (const Req& r : reqs) {
+        HIP_TRY(hipMalloc(r.p, r.n));
+        h->bytes += r.n;
+    }
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+
+    // PSF spectra: direct DFT of the (py x px) support in float64 on the device
+    {
+        void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
+        RL_TRY(ctx->twiddles(h->ly, RL_F64, &wy));
+        RL_TRY(ctx->twiddles(h->lx, RL_F64, &wx));
+        const size_t np = V * h->py * h->px;
+        HIP_TRY(hipMalloc(&psf_dev, np * 8));
+        HIP_TRY(hipMalloc(&s1, V * h->py * h->kx * 16));
+        HIP_TRY(hipMemcpyAsync(psf_dev, psfs, np * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat, h->V, h->py, h->px,
+                                        h->ly, h->lx, h->kx, h->pitch, ctx->stream);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        hipFree(psf_dev);
+        hipFree(s1);
+        HIP_TRY(e);
+        HIP_TRY(e2);
+    }
+    // H_t(ones), line_sted_tools.py:589-592: sum_v clamp(conv(ones, psf_v))
+    HIP_TRY(aux_fill(h->dtype, h->est, h->n_img(), 1.0, ctx->stream));
+    {
+        const int keepB = h->B;
+        h->B = 1;
+        int r = h->row(ROW_FWD, 1, nullptr, h->spec_a, h->est, nullptr, nullptr);
+        if (r == RL_OK) r = h->col(h->spec_a, h->spec_b, 1, true);
+        if (r == RL_OK) r = h->row(ROW_ADJ, 1, h->spec_b, nullptr, nullptr, h->norm, nullptr);
+        h->B = keepB;
+        RL_TRY(r);
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RL_OK;
+}
+
+int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px, int batch, int ny, int nx, int dtype,
+                     rl_deconv** out) {
+    if (!ctx || !psfs || !out) return fail(RL_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_psf < 1 || py < 1 || px < 1 || batch < 1 || ny < 1 || nx < 1) return fail(RL_ERR_INVALID, "non-positive size");
+    if (dtype != RL_F32 && dtype != RL_F64) return fail(RL_ERR_INVALID, "dtype must be RL_F32 or RL_F64");
+    if ((long long)batch * n_psf > 65535) return fail(RL_ERR_UNSUPPORTED, "batch * n_psf exceeds 65535 (grid.y)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    rl_deconv* h = new rl_deconv;
+    h->ctx = ctx;
+    h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
+    int r = deconv_build(h, psfs);
+    if (r != RL_OK) {
+        std::string keep = g_err;
+        rl_deconv_destroy(h);
+        g_err = keep;
+        return r;
+    }
+    *out = h;
+    return RL_OK;
+}
+
+int rl_deconv_info(const rl_deconv* h, int* ly, int* lx, int* pitch, size_t* device_bytes) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (ly) *ly = h->ly;
+    if (lx) *lx = h->lx;
+    if (pitch) *pitch = h->pitch;
+    if (device_bytes) *device_bytes = h->bytes;
+    return RL_OK;
+}
+
+int rl_deconv_set_object(rl_deconv* h, const double* obj, const double* total_brightness) {
+    if (!h || !obj) return fail(RL_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    const size_t n = h->n_img();
+    h->stage.resize((size_t)h->B * n);
+    for (int f = 0; f < h->B; ++f) {
+        const double* src = obj + (size_t)f * n;
+        double* dst = h->stage.data() + (size_t)f * n;
+        if (total_brightness) {                       // :505-506  obj *= total_brightness / obj.sum()
+            double s = 0.0;
+            for (size_t i = 0; i < n; ++i) s += src[i];
+            const double k = total_brightness[f] / s;
+            for (size_t i = 0; i < n; ++i) dst[i] = src[i] * k;
+        } else {
+            std::memcpy(dst, src, n * 8);
+        }
+    }
+    RL_TRY(h->upload(h->stage.data(), h->obj, (size_t)h->B * n));
+    HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
+    RL_TRY(h->forward_object());
+    HIP_TRY(hipEventRecord(h->ev1, h->ctx->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_sim_ms = ms;
+    h->have_obj = true;
+    h->spec_valid = false;
+    return RL_OK;
+}
+
+int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (!h->have_obj) return fail(RL_ERR_STATE, "rl_deconv_set_object has not been called");
+    if (rng_kind != RL_RNG_NONE && rng_kind != RL_RNG_PHILOX) return fail(RL_ERR_INVALID, "unknown rng_kind");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), seed, rng_kind,
+                        h->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    h->have_meas = true;
+    h->est_ready = false;
+    return RL_OK;
+}
+
+int rl_deconv_set_measurement(rl_deconv* h, const double* noisy) {
+    if (!h || !noisy) return fail(RL_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    RL_TRY(h->upload(noisy, h->meas, (size_t)h->B * h->V * h->n_img()));
+    h->have_meas = true;
+    h->est_ready = false;
+    return RL_OK;
+}
+
+int rl_deconv_reset_estimate(rl_deconv* h) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    h->est_ready = false;
+    return RL_OK;
+}
+
+int rl_deconv_iterate(rl_deconv* h, int k) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (k < 0) return fail(RL_ERR_INVALID, "k < 0");
+    if (!h->have_meas) return fail(RL_ERR_STATE, "no measurement: call rl_deconv_simulate or rl_deconv_set_measurement");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
+    if (!h->est_ready) {
+        RL_TRY(h->start_estimate());
+    } else if (!h->spec_valid) {   // H / H_t were called in between: rebuild rowFFT(est)
+        RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->est, nullptr, nullptr));
+        h->spec_valid = true;
+    }
+    for (int i = 0; i < k; ++i) RL_TRY(h->iterate_once());
+    HIP_TRY(hipEventRecord(h->ev1, h->ctx->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_iter_ms = ms;
+    return RL_OK;
+}
+
+#define RL_GETTER(name, buf, count, need, what)                                   \
+    int name(rl_deconv* h, double* out) {                                         \
+        if (!h || !out) return fail(RL_ERR_INVALID, "NULL argument");             \
+        if (!(need)) return fail(RL_ERR_STATE, what " is not available yet");     \
+        HIP_TRY(hipSetDevice(h->ctx->device));                                    \
+        return h->download(h->buf, out, (count));                                 \
+    }
+RL_GETTER(rl_deconv_get_object, obj, (size_t)h->B* h->n_img(), h->have_obj, "object")
+RL_GETTER(rl_deconv_get_noiseless, noiseless, (size_t)h->B* h->V* h->n_img(), h->have_obj, "noiseless measurement")
+RL_GETTER(rl_deconv_get_measurement, meas, (size_t)h->B* h->V* h->n_img(), h->have_meas, "measurement")
+RL_GETTER(rl_deconv_get_estimate, est, (size_t)h->B* h->n_img(), h->est_ready, "estimate")
+RL_GETTER(rl_deconv_get_normalization, norm, h->n_img(), true, "normalization")
+
+int rl_forward(rl_deconv* h, const double* x, double* out) {
+    if (!h || !x || !out) return fail(RL_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    // overwrites spec_a / spec_b; the estimate itself is kept (spec_a is rebuilt by the next iterate)
+    void* xin = h->scratch;   // first B images of scratch
+    RL_TRY(h->upload(x, xin, (size_t)h->B * h->n_img()));
+    RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, xin, nullptr, nullptr));
+    RL_TRY(h->col(h->spec_a, h->spec_b, h->B, true));
+    RL_TRY(h->row(ROW_INV, (unsigned)(h->B * h->V), h->spec_b, nullptr, nullptr, h->scratch, nullptr));
+    h->spec_valid = false;
+    return h->download(h->scratch, out, (size_t)h->B * h->V * h->n_img());
+}
+
+int rl_adjoint(rl_deconv* h, const double* y, double* out, int normalize) {
+    if (!h || !y || !out) return fail(RL_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    RL_TRY(h->upload(y, h->scratch, (size_t)h->B * h->V * h->n_img()));
+    // row transform of every view image: run ROW_FWD with V folded into the frame index
+    RL_TRY(h->row(ROW_FWD, (unsigned)(h->B * h->V), nullptr, h->spec_b, h->scratch, nullptr, nullptr));
+    RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false));
+    RL_TRY(h->row(ROW_ADJ, (unsigned)h->B, h->spec_b, nullptr, nullptr, h->scratch, normalize ? h->norm : nullptr));
+    h->spec_valid = false;
+    return h->download(h->scratch, out, (size_t)h->B * h->n_img());
+}
+
+int rl_deconv_last_ms(const rl_deconv* h, double* iterate_ms, double* simulate_ms) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (iterate_ms) *iterate_ms = h->last_iter_ms;
+    if (simulate_ms) *simulate_ms = h->last_sim_ms;
+    return RL_OK;
+}
+
+int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t seed, double* total_ms) {
+    if (!h || !total_ms) return fail(RL_ERR_INVALID, "NULL argument");
+    if (!h->have_obj) return fail(RL_ERR_STATE, "rl_deconv_set_object has not been called");
+    if (k < 0 || reps < 1) return fail(RL_ERR_INVALID, "bad k / reps");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    HIP_TRY(hipEventRecord(h->ev0, s));
+    for (int r = 0; r < reps; ++r) {
+        RL_TRY(h->forward_object());                                   // noiseless = H(obj)
+        HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V),
+                            seed + (uint64_t)r, rng_kind, s));         // noisy = Poisson(noiseless) + 1e-9
+        h->have_meas = true;
+        RL_TRY(h->start_estimate());                                   // est = 1
+        for (int i = 0; i < k; ++i) RL_TRY(h->iterate_once());
+    }
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *total_ms = ms;
+    return RL_OK;
+}
+
+
+int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
+    if (!h || !avg_ms) return fail(RL_ERR_INVALID, "NULL argument");
+    if (!h->have_meas) return fail(RL_ERR_STATE, "no measurement");
+    if (reps < 1) return fail(RL_ERR_INVALID, "reps < 1");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    if (!h->est_ready) RL_TRY(h->start_estimate());
+    // one untimed iteration so that every buffer holds realistic data
+    RL_TRY(h->iterate_once());
+    for (int which = 0; which < 6; ++which) {
+        HIP_TRY(hipEventRecord(h->ev0, s));
+        for (int r = 0; r < reps; ++r) {
+            switch (which) {
+                case 0: RL_TRY(h->col(h->spec_a, h->spec_b, h->B, true)); break;
+                case 1: RL_TRY(h->row(ROW_RATIO, (unsigned)(h->B * h->V), h->spec_b, h->spec_b, h->meas, nullptr, nullptr)); break;
+                case 2: RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false)); break;
+                case 3: RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_b, h->spec_a, nullptr, h->est, h->norm)); break;
+                case 4: RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->obj, nullptr, nullptr)); break;
+                case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->scratch, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 1, RL_RNG_PHILOX, s)); break;
+            }
+        }
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        HIP_TRY(hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        avg_ms[which] = (double)ms / reps;
+    }
+    // the repeated launches trashed the RL state on purpose; force a clean restart
+    h->est_ready = false;
+    h->spec_valid = false;
+    return RL_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,317 @@
+"""Drop-in mirror of the reference module figure_generation/line_sted_tools.py.
+
+Same public names, arguments, return-dict keys and error behaviour as the
+reference (citations "ref:NNN" are line numbers in that file); the numerical
+work runs in hand-written HIP kernels on an MI355X through librlsted.so.
+
+    psf_report, generate_psfs, tune_psf, get_width     -> psf.py (device PSF kernels)
+    Deconvolver (H, H_t, create_data_from_object, iterate, record_*)
+    logarithmic_progress
+
+plus batch-oriented helpers that the reference lacks (`simulate`,
+`deconvolve`), which process many independent frames per launch.
+
+Precision: the reference computes in float64.  `Deconvolver(dtype=...)` picks
+the device arithmetic: 'f64' (default for this class: bit-level agreement with
+the reference to ~1e-12) or 'f32' (the BASELINE throughput mode, <=1e-5
+normwise at 20 iterations).  Environment variable RLSTED_DTYPE overrides the
+default.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeconvPlan, RNG_NONE, RNG_PHILOX
+
+_DEFAULT_DTYPE = os.environ.get('RLSTED_DTYPE', 'f64')
+_DEFAULT_DEVICE = int(os.environ.get('RLSTED_DEVICE', '0'))
+
+
+def _np_tif():
+    from . import np_tif
+    return np_tif
+
+
+class Deconvolver:
+    """ref:478-594.  One PSF list ("views"), measurements as Python lists of
+    (nz, ny, nx) float64 arrays, estimate updated in place by iterate()."""
+
+    def __init__(self, psfs, output_prefix=None, verbose=True, dtype=None,
+                 device=None, rng='numpy'):
+        """'psfs' is a list of numpy arrays, one for each PSF (ref:479-494).
+        dtype/device/rng are extensions: device arithmetic type, GPU index and
+        the Poisson generator ('numpy' = the reference's np.random.poisson on
+        the host, 'philox' = counter-based generator on the device)."""
+        self.psfs = list(psfs)
+        if output_prefix is None:
+            output_prefix = os.getcwd()
+        if not os.path.exists(os.path.dirname(output_prefix)):
+            os.mkdir(os.path.dirname(output_prefix))
+        self.output_prefix = output_prefix
+        self.verbose = verbose
+        self.num_iterations = 0
+        self.saved_iterations = []
+        self.estimate_history = []
+        self.dtype = dtype or _DEFAULT_DTYPE
+        self.device = _DEFAULT_DEVICE if device is None else device
+        self.rng = rng
+        for p in self.psfs:
+            if np.ndim(p) != 3 or np.shape(p)[0] != 1:
+                raise NotImplementedError(
+                    'device path supports 2-D PSFs of shape (1, py, px); got %s' % (np.shape(p),))
+        self._plan = None
+        self._estimate = None
+        self._estimate_stale = False
+        return None
+
+    # ---- device plan management -------------------------------------------
+    def _plan_for(self, shape):
+        nz, ny, nx = shape
+        p = self._plan
+        if p is None or (p.B, p.ny, p.nx) != (nz, ny, nx):
+            self._plan = DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)
+            if hasattr(self, 'H_t_normalization'):
+                del self.H_t_normalization
+        return self._plan
+
+    # ---- data ---------------------------------------------------------------
+    def create_data_from_object(self, obj, total_brightness=None, random_seed=None):
+        assert len(obj.shape) == 3                      # ref:502
+        assert obj.dtype == np.float64                  # ref:503
+        plan = self._plan_for(obj.shape)
+        plan.set_object(obj, None if total_brightness is None
+                        else self._brightness(obj, total_brightness))
+        self.true_object = plan.object()
+        noiseless = plan.noiseless()                    # (nz, V, ny, nx)
+        self.noiseless_measurement = [np.ascontiguousarray(noiseless[:, v]) for v in range(plan.V)]
+        if self.rng == 'numpy':
+            if random_seed is not None:
+                np.random.seed(random_seed)             # ref:508-509 (global state, like the reference)
+            self.noisy_measurement = [np.random.poisson(m) + 1e-9     # ref:510
+                                      for m in self.noiseless_measurement]
+            plan.set_measurement(np.stack(self.noisy_measurement, axis=1))
+        elif self.rng == 'philox':
+            plan.simulate(seed=0 if random_seed is None else int(random_seed), rng=RNG_PHILOX)
+            noisy = plan.measurement()
+            self.noisy_measurement = [np.ascontiguousarray(noisy[:, v]) for v in range(plan.V)]
+        else:
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self._measurement_on_device = True
+        return None
+
+    @staticmethod
+    def _brightness(obj, total_brightness):
+        """The reference scales the whole (nz, ny, nx) stack by one factor
+        total_brightness / obj.sum() (ref:505-506); the plan scales per frame to
+        a per-frame target, so hand it each frame's share of the total."""
+        total = obj.sum()
+        return np.array([total_brightness * obj[z].sum() / total for z in range(obj.shape[0])])
+
+    def load_data_from_tif(self, filename):
+        """ref:514-518.  The reference asserts `shape == 3`, which can never hold
+        (dead code there); the intent -- a 3-D stack -- is what is checked here."""
+        data = _np_tif().tif_to_array(filename) + 1e-9
+        assert len(data.shape) == 3
+        assert data.min() >= 0
+        self.noisy_measurement = data
+        self._measurement_on_device = False
+        return None
+
+    # ---- Richardson-Lucy -----------------------------------------------------
+    def _push_measurement(self):
+        m = self.noisy_measurement
+        m = [np.asarray(v) for v in m] if isinstance(m, (list, tuple)) else [np.asarray(m)]
+        plan = self._plan_for(m[0].shape)
+        plan.set_measurement(np.stack(m, axis=1))
+        self._measurement_on_device = True
+        return plan
+
+    def iterate(self):
+        """ref:520-531: estimate *= H_t(measurement / H(estimate))."""
+        if not getattr(self, '_measurement_on_device', False):
+            self._push_measurement()
+        plan = self._plan
+        if self.num_iterations == 0:
+            plan.reset_estimate()
+        self.num_iterations += 1
+        plan.iterate(1)
+        self._estimate_stale = True
+        return None
+
+    def iterate_many(self, k):
+        """k iterations without returning to Python in between (extension)."""
+        if not getattr(self, '_measurement_on_device', False):
+            self._push_measurement()
+        if self.num_iterations == 0:
+            self._plan.reset_estimate()
+        self.num_iterations += k
+        self._plan.iterate(k)
+        self._estimate_stale = True
+
+    @property
+    def estimate(self):
+        if self._estimate_stale:
+            self._estimate = self._plan.estimate()
+            self._estimate_stale = False
+        if self._estimate is None:
+            raise AttributeError('estimate')          # like the reference before iterate()
+        return self._estimate
+
+    # ---- operators -------------------------------------------------------------
+    def H(self, x):
+        """ref:567-577: list, one blurred (clamped >= 0) image stack per PSF."""
+        x = np.asarray(x, dtype=np.float64)
+        plan = self._plan_for(x.shape)
+        out = plan.forward(x)
+        return [np.ascontiguousarray(out[:, v]) for v in range(plan.V)]
+
+    def H_t(self, y, normalize=True):
+        """ref:579-594."""
+        y = [np.asarray(v, dtype=np.float64) for v in y]
+        plan = self._plan_for(y[0].shape)
+        if normalize and not hasattr(self, 'H_t_normalization'):
+            self.H_t_normalization = plan.normalization().reshape(1, plan.ny, plan.nx) * np.ones((plan.B, 1, 1))
+        return plan.adjoint(np.stack(y, axis=1), normalize=normalize)
+
+    # ---- recording (host I/O, ref:533-565) ---------------------------------
+    def record_iteration(self, save_tifs=True):
+        self.saved_iterations.append(self.num_iterations)
+        self.estimate_history.append(self.estimate.copy())
+        if save_tifs:
+            np_tif = _np_tif()
+            eh = np.squeeze(np.concatenate(self.estimate_history, axis=0))
+            np_tif.array_to_tif(eh, self.output_prefix + 'estimate_history.tif')
+
+            def f(x):
+                if len(x.shape) == 2:
+                    x = x.reshape(1, x.shape[0], x.shape[1])
+                return np.log(1 + np.abs(np.fft.fftshift(
+                    np.fft.fftn(x, axes=(1, 2)), axes=(1, 2))))
+            np_tif.array_to_tif(f(eh - self.true_object),
+                                self.output_prefix + 'estimate_FT_error_history.tif')
+        return None
+
+    def record_data(self):
+        np_tif = _np_tif()
+        if hasattr(self, 'psfs'):
+            psfs = np.squeeze(np.concatenate(self.psfs, axis=0))
+            np_tif.array_to_tif(psfs, self.output_prefix + 'psfs.tif')
+        if hasattr(self, 'true_object'):
+            np_tif.array_to_tif(self.true_object, self.output_prefix + 'object.tif')
+        if hasattr(self, 'noiseless_measurement'):
+            nm = np.squeeze(np.concatenate(self.noiseless_measurement, axis=0))
+            np_tif.array_to_tif(nm, self.output_prefix + 'noiseless_measurement.tif')
+        if hasattr(self, 'noisy_measurement'):
+            nm = np.squeeze(np.concatenate(self.noisy_measurement, axis=0))
+            np_tif.array_to_tif(nm, self.output_prefix + 'noisy_measurement.tif')
+        return None
+
+
+# ---------------------------------------------------------------------------
+# Batch API (extension): many independent frames per launch.  One "frame" is
+# one (object, seed) pair imaged through the plan's PSF set.
+# ---------------------------------------------------------------------------
+def simulate(objects, psfs, total_brightness=None, seed=0, dtype='f32', device=None,
+             rng='philox', plan=None):
+    """create_data_from_object for a batch: objects (B, ny, nx) float array.
+    Returns (plan, noiseless (B,V,ny,nx), noisy (B,V,ny,nx))."""
+    objects = np.asarray(objects, dtype=np.float64)
+    B, ny, nx = objects.shape
+    if plan is None:
+        plan = DeconvPlan(psfs, B, ny, nx, dtype=dtype,
+                          device=_DEFAULT_DEVICE if device is None else device)
+    plan.set_object(objects, total_brightness)
+    if rng == 'philox':
+        plan.simulate(seed=seed, rng=RNG_PHILOX)
+    elif rng == 'none':
+        plan.simulate(seed=seed, rng=RNG_NONE)
+    elif rng == 'numpy':
+        if seed is not None:
+            np.random.seed(seed)
+        plan.set_measurement(np.random.poisson(plan.noiseless()) + 1e-9)
+    else:
+        raise ValueError("rng must be 'philox', 'numpy' or 'none'")
+    return plan, plan.noiseless(), plan.measurement()
+
+
+def deconvolve(measurement, psfs, iterations, dtype='f32', device=None, plan=None):
+    """K Richardson-Lucy iterations on a batch: measurement (B, V, ny, nx).
+    Returns the estimates (B, ny, nx)."""
+    measurement = np.asarray(measurement, dtype=np.float64)
+    B, V, ny, nx = measurement.shape
+    if plan is None:
+        plan = DeconvPlan(psfs, B, ny, nx, dtype=dtype,
+                          device=_DEFAULT_DEVICE if device is None else device)
+    plan.set_measurement(measurement)
+    plan.reset_estimate()
+    plan.iterate(iterations)
+    return plan.estimate()
+
+
+def _save_points(n):
+    """Indices flagged by logarithmic_progress for an n-long iterable: the powers
+    of two p with p + 1 < n, and the final index (ref:618-623)."""
+    points, p = set(), 1
+    while p + 1 < n:
+        points.add(p)
+        p *= 2
+    points.add(n - 1)
+    return points
+
+
+class _ProgressPrinter:
+    """Textual progress display of ref:624-651: silent for the first 1.5 s, then a
+    65-column star bar that restarts (with a rate line) at every save point."""
+    RULER = ("Progress:\n|0%" + " " * 13 + "|" + " " * 15 + "|50%" +
+             " " * 12 + "|" + " " * 15 + "|100%")
+
+    def __init__(self, n, points):
+        self.n, self.points = n, points
+        self.t0 = time.perf_counter()
+        self.ruler_shown = False
+        self.stars = 0
+
+    def step(self, i):
+        elapsed = time.perf_counter() - self.t0
+        if elapsed <= 1.5:
+            return
+        if i in self.points:
+            rate = i / elapsed
+            print("Iteration %d/%d %0.1fs elapsed, ~%0.1fs remaining, %0.1f iter/s"
+                  % (i, self.n - 1, elapsed, (self.n - i) / rate, rate))
+            self.ruler_shown, self.stars = False, 0
+        if not self.ruler_shown:
+            print(self.RULER)
+            self.ruler_shown = True
+        while self.stars / 65 < i / self.n:
+            print("*", end='')
+            self.stars += 1
+        if (i + 1) in self.points:
+            print()
+
+
+def logarithmic_progress(iterable, verbose=True):
+    """ref:596-651.  Generator of (item, flag) pairs; flag is True when the
+    item's index is a power of two or the last one -- the moments the reference
+    saves results.  An empty iterable is returned unchanged, as in the
+    reference.  With verbose=True a progress bar appears after 1.5 s."""
+    n = len(iterable)
+    if n == 0:
+        return iterable
+    points = _save_points(n)
+    printer = _ProgressPrinter(n, points) if verbose else None
+    for i, item in enumerate(iterable):
+        yield (item, i in points)
+        if printer is not None:
+            printer.step(i)
+
+
+def __getattr__(name):
+    # PSF generation lives in psf.py; resolved lazily so that importing the
+    # Deconvolver does not require it.
+    if name in ('psf_report', 'generate_psfs', 'tune_psf', 'get_width'):
+        from . import psf
+        return getattr(psf, name)
+    raise AttributeError(name)

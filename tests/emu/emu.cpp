@@ -14,6 +14,7 @@
 
 #include "../../rescan_line_sted_amd/csrc/conv_kernels.hpp"
 #include "../../rescan_line_sted_amd/csrc/fft_configs.hpp"
+#include "../../rescan_line_sted_amd/csrc/philox_poisson.hpp"
 
 using namespace rl;
 
@@ -136,5 +137,15 @@ int emu_row_f64(int L, int mode, const double* spec_in, double* spec_out, const 
 int emu_row_f32(int L, int mode, const float* spec_in, float* spec_out, const float* src, float* dst,
                 const float* norm, const float* scale, int ny, int nx, int pitch, int V, int gy) {
     DISPATCH_L(L, (row_t<LL, float>(mode, spec_in, spec_out, src, dst, norm, scale, ny, nx, pitch, V, gy)))
+}
+
+// host build of the device Poisson sampler (philox_poisson.hpp)
+int emu_poisson(const double* lam, int n, unsigned long long seed, unsigned image, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = philox_poisson(lam[i], seed, image, (unsigned)i);
+    return 0;
+}
+void emu_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
+    Philox4 o = philox4x32_10(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out[i] = o.x[i];
 }
 }

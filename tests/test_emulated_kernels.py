@@ -24,11 +24,11 @@ def emu():
     so = os.path.join(EMU_DIR, 'libemu.so')
     src = os.path.join(EMU_DIR, 'emu.cpp')
     deps = [src] + [os.path.join(ROOT, 'rescan_line_sted_amd', 'csrc', f)
-                    for f in ('conv_kernels.hpp', 'fft_core.hpp', 'fft_configs.hpp')]
+                    for f in ('conv_kernels.hpp', 'fft_core.hpp', 'fft_configs.hpp', 'philox_poisson.hpp')]
     if (not os.path.exists(so) or
             os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps)):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared',
-                               '-pthread', src, '-o', so])
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+                               '-Wno-unknown-pragmas', '-pthread', src, '-o', so])
     return ctypes.CDLL(so)
 
 

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI / ctypes) with the CPU oracle and
+with the committed golden vectors of the reference.  Needs an MI355X.
+
+Tolerances (stated once):
+  f64 plans : agreement with the float64 reference to 1e-10 normwise, 1e-8
+              pixelwise on RL estimates (same arithmetic, different FFT sizes)
+  f32 plans : <= 1e-5 normwise (max|a-b| / max|b|) up to 20 RL iterations --
+              the BASELINE.json tolerance; a single convolution <= 2e-6.
+"""
+import numpy as np
+import pytest
+
+from conftest import max_rel
+from oracle import line_sted_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+F64_TOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def st():
+    from rescan_line_sted_amd import line_sted_tools
+    return line_sted_tools
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from rescan_line_sted_amd import _lib
+    assert _lib.device_count() >= 1, 'no GPU visible'
+    return _lib
+
+
+def pixelwise(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+# ---------------------------------------------------------------- H / H_t
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 2e-6)])
+def test_g4_conv_conventions(st, golden, dtype, tol, tmp_path):
+    g = golden('g4_conv')
+    for name in ('odd', 'even', 'row', 'big', 'two'):
+        x, psfs, y = g[name + '/x'], g[name + '/psfs'], g[name + '/y']
+        d = st.Deconvolver(list(psfs), output_prefix=str(tmp_path) + '/', verbose=False, dtype=dtype)
+        H = d.H(x)
+        for i in range(len(psfs)):
+            assert max_rel(H[i], g[name + '/H'][i]) < tol, (name, i)
+        assert max_rel(d.H_t(list(y), normalize=False), g[name + '/Ht_raw']) < tol, name
+        assert max_rel(d.H_t(list(y)), g[name + '/Ht']) < 5 * tol, name
+        assert max_rel(d.H_t_normalization, g[name + '/norm']) < tol, name
+
+
+# ------------------------------------------------ simulate + RL vs goldens
+@pytest.mark.parametrize('run,ks', [('rings_point_1p5x', (1, 2, 5, 20, 100)),
+                                    ('rings_line4_2p0x', (1, 5, 20)),
+                                    ('cat_line1_1p0x', (5,))])
+def test_g5_rl_f64_matches_reference(lib, golden, run, ks):
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    psf_set = [p[None] for p in psfs[str(g[run + '/psf_key'])][:, 0]]
+    obj = objs[str(g[run + '/object'])].astype(np.float64)
+    plan = lib.DeconvPlan(psf_set, 1, obj.shape[1], obj.shape[2], dtype='f64')
+    plan.set_object(obj, 5e10)
+    assert max_rel(plan.noiseless()[0], g[run + '/noiseless'][:, 0]) < 1e-12
+    assert max_rel(plan.normalization(), g[run + '/norm'][0]) < 1e-12
+    plan.set_measurement(g[run + '/noisy'][:, 0][None])
+    done = 0
+    for k in ks:
+        plan.iterate(k - done)
+        done = k
+        ref = g[run + '/estimate_%d' % k][0]
+        est = plan.estimate()[0]
+        assert max_rel(est, ref) < F64_TOL, (run, k)
+        assert pixelwise(est, ref) < 1e-8, (run, k)
+
+
+@pytest.mark.parametrize('run,ks', [('rings_point_1p5x', (1, 5, 20)),
+                                    ('rings_line4_2p0x', (1, 5, 20))])
+def test_g5_rl_f32_within_baseline_tolerance(lib, golden, run, ks):
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    psf_set = [p[None] for p in psfs[str(g[run + '/psf_key'])][:, 0]]
+    obj = objs[str(g[run + '/object'])].astype(np.float64)
+    plan = lib.DeconvPlan(psf_set, 1, obj.shape[1], obj.shape[2], dtype='f32')
+    plan.set_object(obj, 5e10)
+    assert max_rel(plan.noiseless()[0], g[run + '/noiseless'][:, 0]) < 2e-6
+    plan.set_measurement(g[run + '/noisy'][:, 0][None])
+    done = 0
+    for k in ks:
+        plan.iterate(k - done)
+        done = k
+        assert max_rel(plan.estimate()[0], g[run + '/estimate_%d' % k][0]) < F32_TOL, (run, k)
+
+
+def test_drop_in_deconvolver_reproduces_reference_run(st, golden, tmp_path):
+    """The reference's own call sequence (line_sted_figure_2.py:39-56) through
+    the mirror class, numpy RNG on the host, f64 device arithmetic."""
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    run = 'rings_point_1p5x'
+    d = st.Deconvolver(list(psfs['1p5x_lr/point_sted_psf']), str(tmp_path) + '/x_', verbose=False)
+    d.create_data_from_object(objs['rings'].astype(np.float64), total_brightness=5e10, random_seed=0)
+    assert max_rel(d.noiseless_measurement[0], g[run + '/noiseless'][0]) < 1e-12
+    # same lambda to 1e-13 and the same MT19937 stream -> the same Poisson draws
+    assert (d.noisy_measurement[0] == g[run + '/noisy'][0]).mean() > 0.999
+    d.noisy_measurement = [g[run + '/noisy'][0]]
+    d._measurement_on_device = False
+    for i, save in st.logarithmic_progress(range(5), verbose=False):
+        d.iterate()
+        if save:
+            d.record_iteration(save_tifs=False)
+    assert d.num_iterations == 5 and d.saved_iterations == [2, 3, 5]
+    assert max_rel(d.estimate, g[run + '/estimate_5']) < F64_TOL
+    assert d.estimate.shape == (1, 128, 128) and d.estimate.dtype == np.float64
+
+
+# ----------------------------------------- BASELINE size: 512 x 512, K = 20
+@pytest.fixture(scope='module')
+def astronaut512(golden):
+    obj = golden('objects')['astronaut'].astype(np.float64)
+    return np.kron(obj, np.ones((1, 4, 4)))
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', F32_TOL), ('f64', F64_TOL)])
+def test_512_point_sted_cycle_vs_oracle(lib, golden, astronaut512, dtype, tol):
+    psf = golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf']
+    K = 20
+    d = orc.Deconvolver(list(psf))
+    d.create_data_from_object(astronaut512, total_brightness=8e11, random_seed=1)
+    plan = lib.DeconvPlan(list(psf), 1, 512, 512, dtype=dtype)
+    assert plan.info()['ly'] == 576 and plan.info()['lx'] == 576
+    plan.set_object(astronaut512, 8e11)
+    assert max_rel(plan.noiseless()[0, 0], d.noiseless_measurement[0][0]) < (2e-6 if dtype == 'f32' else 1e-12)
+    plan.set_measurement(np.array(d.noisy_measurement)[:, 0][None])
+    plan.iterate(K)
+    for _ in range(K):
+        d.iterate()
+    assert max_rel(plan.estimate()[0], d.estimate[0]) < tol
+
+
+def test_batch_of_frames_equals_frames_run_alone(lib, golden, astronaut512):
+    psfs = [p[None] for p in golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][:, 0]]
+    rng = np.random.default_rng(7)
+    objs = np.stack([astronaut512[0], np.flipud(astronaut512[0]), rng.random((512, 512)) * 255])
+    plan = lib.DeconvPlan(psfs, 3, 512, 512, dtype='f32')
+    plan.set_object(objs, [8e11, 4e11, 1e11])
+    plan.simulate(seed=11)
+    plan.iterate(3)
+    est, noisy = plan.estimate(), plan.measurement()
+    one = lib.DeconvPlan(psfs, 1, 512, 512, dtype='f32')
+    for f, tb in enumerate([8e11, 4e11, 1e11]):
+        one.set_object(objs[f:f + 1], tb)
+        one.set_measurement(noisy[f:f + 1])
+        one.iterate(3)
+        assert np.array_equal(one.estimate()[0], est[f])      # bitwise: no cross-frame coupling
+
+
+# ---------------------------------------------- size independent properties
+@pytest.mark.parametrize('shape', [(512, 512), (500, 317), (129, 64), (2, 3)])
+def test_operator_properties(lib, golden, shape):
+    ny, nx = shape
+    psf = golden('g8_fig2_psfs')['1p5x_lr/line_sted_psfs'][:, 0]
+    psfs = [p[None] for p in psf]
+    rng = np.random.default_rng(ny * 1000 + nx)
+    plan = lib.DeconvPlan(psfs, 2, ny, nx, dtype='f64')
+    x, z = rng.random((2, ny, nx)), rng.random((2, ny, nx))
+    y = rng.random((2, len(psfs), ny, nx))
+    Hx, Hz = plan.forward(x), plan.forward(z)
+    assert max_rel(plan.forward(2 * x + 3 * z), 2 * Hx + 3 * Hz) < 1e-12          # linearity
+    assert Hx.min() >= 0                                                           # clamp
+    # adjoint identity (PSFs are point symmetric to ~1e-3 only after rotation, so use the flipped PSF set)
+    flipped = lib.DeconvPlan([p[:, ::-1, ::-1] for p in psfs], 2, ny, nx, dtype='f64')
+    lhs = float((Hx * y).sum())
+    rhs = float((x * flipped.adjoint(y, normalize=False)).sum())
+    assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+    ones = np.ones((2, len(psfs), ny, nx))
+    assert max_rel(plan.adjoint(ones, normalize=True), np.ones((2, ny, nx))) < 1e-12   # H_t(ones) == ones
+    # energy: with zero padding, sum(H x) <= sum(psf) * sum(x)
+    for v, p in enumerate(psfs):
+        assert Hx[:, v].sum() <= p.sum() * x.sum() * (1 + 1e-12)
+
+
+def test_rl_preserves_flux_and_positivity(lib, golden, astronaut512):
+    psf = golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf']
+    plan = lib.DeconvPlan(list(psf), 1, 512, 512, dtype='f32')
+    plan.set_object(astronaut512, 8e11)
+    plan.simulate(seed=3)
+    plan.iterate(20)
+    est = plan.estimate()[0]
+    assert np.isfinite(est).all() and est.min() >= 0
+    # RL with H_t(ones)-normalisation conserves the measured counts through H
+    again = plan.forward(est[None])[0, 0]
+    meas = plan.measurement()[0, 0]
+    assert abs(again.sum() - meas.sum()) < 1e-3 * meas.sum()
+
+
+# ------------------------------------------------------------ device Poisson
+def test_device_poisson_bit_exact_vs_oracle_twin(lib, golden):
+    from oracle import philox_poisson as pp
+    psf = golden('g8_fig2_psfs')['1p5x_lr/line_sted_psfs'][:, 0]
+    psfs = [p[None] for p in psf]
+    obj = golden('objects')['rings'].astype(np.float64)
+    objs = np.stack([obj[0], obj[0].T])
+    for dtype in ('f64', 'f32'):
+        plan = lib.DeconvPlan(psfs, 2, 128, 128, dtype=dtype)
+        # tiny, moderate and huge rates: multiplication method, PTRS slow path, PTRS fast path
+        for tb, seed in ((3e3, 1), (4e5, 2), (5e10, 0xDEADBEEFCAFE)):
+            plan.set_object(objs, tb)
+            plan.simulate(seed=seed)
+            lam = plan.noiseless().reshape(-1, 128, 128)      # exactly the rates the device used
+            want = pp.noisy_measurement(lam, seed)
+            if dtype == 'f32':
+                want = want.astype(np.float32).astype(np.float64)
+            got = plan.measurement().reshape(-1, 128, 128)
+            assert np.array_equal(got, want), (dtype, tb)
+
+
+def test_edge_cases(lib):
+    rng = np.random.default_rng(0)
+    # PSF larger than the image, 1-pixel image, single row / column
+    for (ny, nx, py, px) in ((3, 4, 9, 11), (1, 1, 5, 5), (1, 37, 3, 7), (41, 1, 7, 3)):
+        psfs = [rng.random((1, py, px))]
+        x = rng.random((1, ny, nx))
+        plan = lib.DeconvPlan(psfs, 1, ny, nx, dtype='f64')
+        ref = orc.Deconvolver(psfs).H(x)[0]
+        assert max_rel(plan.forward(x)[0, 0], ref[0]) < 1e-12
+    # all-zero object: noiseless 0, Poisson(0) + 1e-9 = 1e-9, RL stays finite
+    plan = lib.DeconvPlan([rng.random((1, 5, 5))], 1, 16, 16, dtype='f64')
+    plan.set_object(np.zeros((1, 16, 16)))
+    plan.simulate(seed=1)
+    assert np.all(plan.measurement() == 1e-9)
+    plan.iterate(2)
+    assert np.isfinite(plan.estimate()).all()
+    # errors are reported, not swallowed
+    with pytest.raises(lib.RlstedError):
+        lib.DeconvPlan([rng.random((1, 5, 5))], 1, 4000, 4000, dtype='f32')    # > largest built length
+    fresh = lib.DeconvPlan([rng.random((1, 5, 5))], 1, 16, 16)
+    with pytest.raises(lib.RlstedError):
+        fresh.iterate(1)                                                          # no measurement yet
