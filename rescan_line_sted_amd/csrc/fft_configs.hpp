@@ -18,7 +18,7 @@ struct CfgFor<64> {   // unit-test size
 };
 template <>
 struct CfgFor<192> {  // 128 + 53
-    using Cfg = FftCfg<192, 48, 4, 6, 8>;
+    using Cfg = FftCfg<192, 64, 3, 8, 8>;
     static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
 };
 template <>

@@ -23,18 +23,21 @@ struct DevSync {
     __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 
-template <int C, typename T>
-__global__ void __launch_bounds__(Cfg::T* C) k_colconv(const ColParams<T> p) {
+// NOTE: the transform length is a template parameter of the kernels so that the
+// kernels of different lengths (built in separate translation units) have
+// distinct symbol names.
+template <int L, int C, typename T>
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C) k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    colconv_body<Cfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    colconv_body<typename CfgFor<L>::Cfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 
-template <int Q, int MODE, typename T>
-__global__ void __launch_bounds__(Cfg::T* Q) k_rowpass(const RowParams<T> p) {
+template <int L, int Q, int MODE, typename T>
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q) k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    rowpass_body<Cfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    rowpass_body<typename CfgFor<L>::Cfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 
 template <int C, typename T>
@@ -45,14 +48,14 @@ static constexpr size_t lds_bytes() {
 template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
-    k_colconv<C, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    k_colconv<RL_CFG_L, C, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
     return hipGetLastError();
 }
 
 template <int Q, int MODE, typename T>
 static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
-    k_rowpass<Q, MODE, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
+    k_rowpass<RL_CFG_L, Q, MODE, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
     return hipGetLastError();
 }
 
@@ -88,18 +91,18 @@ template <int Q, typename T>
 static hipError_t prepare_rows() {
     hipError_t e;
     const size_t b = lds_bytes<Q, T>();
-    if ((e = allow_lds(k_rowpass<Q, ROW_FWD, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<Q, ROW_INV, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<Q, ROW_RATIO, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<Q, ROW_UPDATE, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<Q, ROW_ADJ, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_FWD, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_INV, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_RATIO, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, T>, b)) != hipSuccess) return e;
     return hipSuccess;
 }
 
 static hipError_t prepare() {
     hipError_t e;
-    if ((e = allow_lds(k_colconv<kC32, float>, lds_bytes<kC32, float>())) != hipSuccess) return e;
-    if ((e = allow_lds(k_colconv<kC64, double>, lds_bytes<kC64, double>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, float>, lds_bytes<kC32, float>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, double>, lds_bytes<kC64, double>())) != hipSuccess) return e;
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
     return hipSuccess;

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -22,6 +23,7 @@ using namespace rl;
 namespace {
 
 thread_local std::string g_err;
+const bool g_debug_sync = getenv("RLSTED_DEBUG_SYNC") != nullptr;   // sync + check after every launch
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -154,6 +156,12 @@ struct rl_deconv {
             auto p = colp<double>(in, out, h_mode);
             HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
         }
+        if (g_debug_sync) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess)
+                return fail(RL_ERR_HIP, "column kernel L=" + std::to_string(ly) + " grid " + std::to_string(gx) + "x" +
+                                            std::to_string(gy) + ": " + hipGetErrorString(e));
+        }
         return RL_OK;
     }
     template <typename T>
@@ -171,6 +179,13 @@ struct rl_deconv {
         const int Q = tx->Q[dtype];
         const unsigned pairs = (unsigned)((ny + 1) / 2);
         HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
+        if (g_debug_sync) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess)
+                return fail(RL_ERR_HIP, "row kernel mode " + std::to_string(mode) + " L=" + std::to_string(lx) + " grid " +
+                                            std::to_string((pairs + Q - 1) / Q) + "x" + std::to_string(gy) + ": " +
+                                            hipGetErrorString(e));
+        }
         return RL_OK;
     }
     int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
