@@ -39,7 +39,7 @@ def workload():
     objs = np.load(os.path.join(ROOT, 'tests', 'golden', 'objects.npz'))
     psfs = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
     obj = np.kron(objs['astronaut'].astype(np.float64), np.ones((1, 4, 4)))[0]
-    psf = [psfs['2p0x_lr/point_sted_psf'][0][None]]
+    psf = [psfs['2p0x_lr/point_sted_psf'][0]]
     return obj, psf, 5e10 * 16
 
 
