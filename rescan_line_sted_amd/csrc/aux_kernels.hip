@@ -32,7 +32,7 @@ __global__ void k_psf_dft_rows(const double* __restrict__ psf, const double2* __
 // Stage 2: psf_hat[v][ky][kx] = scale * sum_a S1[v][a][kx] * W_Ly[(ky * ((a - cy) mod Ly)) mod Ly]
 template <typename T>
 __global__ void k_psf_dft_cols(const double2* __restrict__ s1, const double2* __restrict__ wy, cx<T>* __restrict__ out,
-                               int py, int ly, int kx, int pitch, double scale) {
+                               int py, int ly, int kx, int pitch, double scale, int transposed) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int ky = blockIdx.y, v = blockIdx.z;
     if (k >= pitch) return;
@@ -47,7 +47,11 @@ __global__ void k_psf_dft_cols(const double2* __restrict__ s1, const double2* __
             im += s.x * w.y + s.y * w.x;
         }
     }
-    out[((size_t)v * ly + ky) * pitch + k] = mk<T>((T)(re * scale), (T)(im * scale));
+    if (transposed) {   // [view][kx][ly]: contiguous along ky for wave-private column transforms
+        if (k < kx) out[((size_t)v * kx + k) * ly + ky] = mk<T>((T)(re * scale), (T)(im * scale));
+    } else {
+        out[((size_t)v * ly + ky) * pitch + k] = mk<T>((T)(re * scale), (T)(im * scale));
+    }
 }
 
 // noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510)
@@ -75,13 +79,14 @@ hipError_t aux_fill(int dtype, void* p, size_t n, double value, hipStream_t s) {
 }
 
 hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev, const void* wy_dev, void* s1_dev,
-                            void* out, int n_psf, int py, int px, int ly, int lx, int kx, int pitch, hipStream_t s) {
+                            void* out, int n_psf, int py, int px, int ly, int lx, int kx, int pitch, int transposed,
+                            hipStream_t s) {
     k_psf_dft_rows<<<dim3((kx + 127) / 128, py, n_psf), 128, 0, s>>>(psf_dev, (const double2*)wx_dev, (double2*)s1_dev, py, px, lx, kx);
     const double scale = 1.0 / ((double)ly * (double)lx);
     if (dtype == DT_F32)
-        k_psf_dft_cols<float><<<dim3((pitch + 127) / 128, ly, n_psf), 128, 0, s>>>((const double2*)s1_dev, (const double2*)wy_dev, (cx<float>*)out, py, ly, kx, pitch, scale);
+        k_psf_dft_cols<float><<<dim3((pitch + 127) / 128, ly, n_psf), 128, 0, s>>>((const double2*)s1_dev, (const double2*)wy_dev, (cx<float>*)out, py, ly, kx, pitch, scale, transposed);
     else
-        k_psf_dft_cols<double><<<dim3((pitch + 127) / 128, ly, n_psf), 128, 0, s>>>((const double2*)s1_dev, (const double2*)wy_dev, (cx<double>*)out, py, ly, kx, pitch, scale);
+        k_psf_dft_cols<double><<<dim3((pitch + 127) / 128, ly, n_psf), 128, 0, s>>>((const double2*)s1_dev, (const double2*)wy_dev, (cx<double>*)out, py, ly, kx, pitch, scale, transposed);
     return hipGetLastError();
 }
 

@@ -7,9 +7,10 @@ namespace rl {
 hipError_t aux_fill(int dtype, void* p, size_t n, double value, hipStream_t s);
 // psf_dev: [n_psf][py][px] float64 on the device.  wx/wy: float64 twiddle tables
 // exp(-2 pi i m / L).  s1_dev: scratch [n_psf][py][kx] complex128.
-// out: [n_psf][ly][pitch] complex of `dtype`, scaled by 1/(ly*lx).
+// out: [n_psf][ly][pitch] complex of `dtype` (or [n_psf][kx][ly] when transposed), scaled by 1/(ly*lx).
 hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev, const void* wy_dev, void* s1_dev,
-                            void* out, int n_psf, int py, int px, int ly, int lx, int kx, int pitch, hipStream_t s);
+                            void* out, int n_psf, int py, int px, int ly, int lx, int kx, int pitch, int transposed,
+                            hipStream_t s);
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img,
                        unsigned long long seed, int rng_kind, hipStream_t s);
 }  // namespace rl

@@ -13,7 +13,9 @@
 //   spectra  cx<T> [img][ny][pitch]   row-transformed half spectra, Kx = Lx/2+1
 //                                     valid columns, pitch = Kx rounded up to 8
 //   psf_hat  cx<T> [view][Ly][pitch]  2-D spectrum of the PSF wrapped around the
-//                                     origin, pre-scaled by 1/(Ly*Lx)
+//                                     origin, pre-scaled by 1/(Ly*Lx); stored
+//                                     transposed [view][Kx][Ly] for wave-private
+//                                     column transforms (Ly config with T == 64)
 // A 2-D circular convolution of size Ly x Lx with Ly >= ny + Py/2, Lx >= nx +
 // Px/2 restricted to rows < ny, columns < nx equals the zero padded 'same'
 // convolution exactly (DESIGN.md "wrap-free sizes").
@@ -93,6 +95,74 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
     }
 }
 
+
+// Column pass for wave-private transforms (Cfg::T == 64): workgroup = C waves,
+// wave w owns spectrum column col0 + w.
+//   1. the whole workgroup loads the [ny][C] tile with coalesced C*8-byte row
+//      segments into LDS, column major (one padded transform per column)
+//   2. each wave: FFT_y -> * psf_hat -> IFFT_y on its own column, in LDS and
+//      registers, no workgroup barrier; result back to its LDS column
+//   3. the whole workgroup stores rows < ny, coalesced as in 1.
+// psf_hat is read transposed here: psf_hat_t[view][kx][Ly] (contiguous along ky).
+template <class Cfg, int C, typename T, class Sync>
+RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
+    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    constexpr int NT = 64 * C;
+    const int w = tid / 64, lane = tid % 64;
+    const int col0 = bx * C;
+    const int frame = by / p.V, view = by % p.V;
+    const size_t img = (size_t)p.ny * p.pitch;
+    const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
+    cx<T>* __restrict__ out = p.out + (size_t)by * img;
+
+    // 1. cooperative tile load (c fastest across lanes), zero fill rows >= ny
+    for (int e = tid; e < L * C; e += NT) {
+        const int row = e / C, c = e % C;
+        cx<T> x = mk<T>((T)0, (T)0);
+        if (row < p.ny && col0 + c < p.kx) x = in[(size_t)row * p.pitch + col0 + c];
+        lds[c * LP + lds_pad(row)] = x;
+    }
+    sync.wg();
+
+    // 2. wave-private transform of column col0 + w
+    const int col = col0 + w;
+    if (col < p.kx) {
+        LdsView<T, 1> view_lds{lds + w * LP};
+        const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
+        cx<T> v[VMAX];
+        run_passes<Cfg, false, 0, false>(v, lane, view_lds, p.tw, sync);
+        using FL = PassInfo<Cfg, false, NP - 1>;
+#pragma unroll
+        for (int nb = 0; nb < FL::NB; ++nb) {
+            const int j = lane + nb * 64;
+            if (j < FL::NBF) {
+#pragma unroll
+                for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[j + r * FL::NBF]);
+            }
+        }
+        run_passes<Cfg, true, 0, true>(v, lane, view_lds, p.tw, sync);
+        using IL = PassInfo<Cfg, true, NP - 1>;
+        sync.wave();   // last pass' LDS reads are done before the column is overwritten
+#pragma unroll
+        for (int nb = 0; nb < IL::NB; ++nb) {
+            const int j = lane + nb * 64;
+            if (j < IL::NBF) {
+#pragma unroll
+                for (int r = 0; r < IL::R; ++r) view_lds.at(j + r * IL::NBF) = v[nb * IL::R + r];
+            }
+        }
+    }
+    sync.wg();
+
+    // 3. cooperative store of rows < ny
+    for (int e = tid; e < p.ny * C; e += NT) {
+        const int row = e / C, c = e % C;
+        if (col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+    }
+}
+
 // -------------------------------- row pass ---------------------------------
 // Two real image rows (2p, 2p+1) ride through one complex transform of length
 // Lx (real row in .re, the next row in .im).  Depending on MODE the body does
@@ -118,7 +188,8 @@ struct RowParams {
     int ny, nx, pitch, V;
 };
 
-template <class Cfg, int Q, int MODE, typename T, class Sync>
+// ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.
+template <class Cfg, int Q, int MODE, bool ONEV, typename T, class Sync>
 RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     constexpr int NP = Cfg::NP, L = Cfg::L, TT = Cfg::T;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
@@ -135,19 +206,19 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
 
     cx<T> v[VMAX];
-    cx<T> acc[MODE == ROW_UPDATE || MODE == ROW_ADJ ? NB * R : 1];
+    cx<T> acc[(MODE == ROW_UPDATE || MODE == ROW_ADJ) && !ONEV ? NB * R : 1];
 
     if constexpr (MODE != ROW_FWD) {
         constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
-        const int nview = MULTI ? p.V : 1;
-        if constexpr (MULTI) {
+        const int nview = (MULTI && !ONEV) ? p.V : 1;
+        if constexpr (MULTI && !ONEV) {
 #pragma unroll
             for (int s = 0; s < NB * R; ++s) acc[s] = mk<T>((T)0, (T)0);
         }
         for (int vw = 0; vw < nview; ++vw) {
             const size_t im = MULTI ? (size_t)by * p.V + vw : (size_t)by;
             const cx<T>* __restrict__ sp = p.spec_in + im * simg;
-            sync();   // LDS free
+            fft_sync<Cfg>(sync);   // LDS free
             // pack the two half spectra into one Hermitian-free complex row
             for (int k = t; k <= L / 2; k += TT) {
                 cx<T> A = mk<T>((T)0, (T)0), B = mk<T>((T)0, (T)0);
@@ -156,9 +227,9 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 view_lds.at(k) = mk<T>(A.re - B.im, A.im + B.re);
                 if (k > 0 && k < L / 2) view_lds.at(L - k) = mk<T>(A.re + B.im, B.re - A.im);
             }
-            sync();
+            fft_sync<Cfg>(sync);
             run_passes<Cfg, true, 0, false>(v, t, view_lds, p.tw, sync);
-            if constexpr (MULTI) {
+            if constexpr (MULTI && !ONEV) {
 #pragma unroll
                 for (int s = 0; s < NB * R; ++s) {
                     acc[s].re += v[s].re > (T)0 ? v[s].re : (T)0;
@@ -193,25 +264,27 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (inx && ok1) z.im = meas[(size_t)r1 * p.nx + i] / (v[s].im > (T)0 ? v[s].im : (T)0);
             } else if constexpr (MODE == ROW_UPDATE) {
                 T* __restrict__ est = p.dst + (size_t)by * rimg;
+                const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    z.re = est[o] * (acc[s].re / p.norm[o]);
+                    z.re = est[o] * (a.re / p.norm[o]);
                     est[o] = z.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    z.im = est[o] * (acc[s].im / p.norm[o]);
+                    z.im = est[o] * (a.im / p.norm[o]);
                     est[o] = z.im;
                 }
             } else if constexpr (MODE == ROW_ADJ) {
                 T* __restrict__ dst = p.dst + (size_t)by * rimg;
+                const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    dst[o] = p.norm ? acc[s].re / p.norm[o] : acc[s].re;
+                    dst[o] = p.norm ? a.re / p.norm[o] : a.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    dst[o] = p.norm ? acc[s].im / p.norm[o] : acc[s].im;
+                    dst[o] = p.norm ? a.im / p.norm[o] : a.im;
                 }
             }
             v[s] = z;
@@ -222,7 +295,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         run_passes<Cfg, false, 0, true>(v, t, view_lds, p.tw, sync);
         // natural-order spectrum to LDS, then split it into the two rows' half spectra
         using FL = PassInfo<Cfg, false, NP - 1>;
-        sync();
+        fft_sync<Cfg>(sync);
 #pragma unroll
         for (int nb = 0; nb < FL::NB; ++nb) {
             const int j = t + nb * TT;
@@ -231,7 +304,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 for (int r = 0; r < FL::R; ++r) view_lds.at(j + r * FL::NBF) = v[nb * FL::R + r];
             }
         }
-        sync();
+        fft_sync<Cfg>(sync);
         cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg;
         for (int k = t; k <= L / 2; k += TT) {
             const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);

@@ -1,6 +1,7 @@
 // fft_configs.hpp -- the supported transform lengths and their geometry.
-// Length L, T threads per transform, forward radix list (the inverse runs it
-// reversed); C = spectrum columns per workgroup in the column kernel and
+// Length L, T threads per transform (T == 64: one wavefront per transform, no
+// workgroup barriers inside a transform), forward radix list (the inverse runs
+// it reversed); C = spectrum columns per workgroup in the column kernel and
 // Q = row pairs per workgroup in the row kernels, for f32 / f64.
 // LDS per workgroup = C * (L*9/8 + 1) * sizeof(complex).
 #pragma once
@@ -18,18 +19,20 @@ struct CfgFor<64> {   // unit-test size
 };
 template <>
 struct CfgFor<192> {  // 128 + 53
-    using Cfg = FftCfg<192, 64, 3, 8, 8>;
-    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+    using Cfg = FftCfg<192, 64, 3, 8, 8>;     // T == 64: wave-private transforms
+    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
 };
 template <>
 struct CfgFor<256> {  // 160 + 53
-    using Cfg = FftCfg<256, 64, 4, 8, 8>;
-    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+    using Cfg = FftCfg<256, 64, 4, 8, 8>;     // wave-private
+    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
 };
 template <>
 struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
-    using Cfg = FftCfg<576, 72, 8, 8, 9>;
-    static constexpr int C32 = 8, C64 = 8, Q32 = 8, Q64 = 8;
+    // wave-private; radix 9 first so that the row kernels' pointwise stage (inverse's
+    // last = forward's first pass) holds elements lane + 64 r: fully coalesced rows
+    using Cfg = FftCfg<576, 64, 9, 8, 8>;
+    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
 };
 template <>
 struct CfgFor<1152> { // 1024 + 53

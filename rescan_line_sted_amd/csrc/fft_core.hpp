@@ -248,19 +248,34 @@ RL_HD void pass_load_lds(cx<T>* v, int t, LdsView<T, CS> lds) {
     }
 }
 
+// A transform whose T threads are exactly one 64-lane wavefront exchanges data
+// through LDS without workgroup barriers: LDS operations of one wave complete
+// in issue order, so only the compiler must be kept from reordering them
+// (Sync::wave()).  Other geometries use workgroup barriers (Sync::wg()).
+template <class Cfg>
+struct WavePrivate {
+    static constexpr bool value = (Cfg::T == 64);
+};
+
+template <class Cfg, class Sync>
+RL_HD void fft_sync(Sync& sync) {
+    if constexpr (WavePrivate<Cfg>::value) sync.wave();
+    else sync.wg();
+}
+
 // Runs passes P..NP-1.  Pass P takes its input from registers when FROM_REGS,
 // otherwise from LDS (natural order).  The last pass leaves its output in
 // registers: slot nb*R + r  <->  element (t + nb*T) + r*NBF of the last pass.
-// Every LDS scatter is bracketed by barriers (all threads of the workgroup
-// must call this).
+// Every LDS scatter is bracketed by syncs (all threads of the transform --
+// the whole workgroup unless the transform is wave private -- must call this).
 template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, int CS, class Sync>
 RL_HD void run_passes(cx<T>* v, int t, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
     if constexpr (!FROM_REGS) pass_load_lds<Cfg, INV, P>(v, t, lds);
     pass_compute<Cfg, INV, P>(v, t, tw);
     if constexpr (P + 1 < Cfg::NP) {
-        sync();   // everyone has finished reading the previous LDS contents
+        fft_sync<Cfg>(sync);   // everyone has finished reading the previous LDS contents
         pass_store_lds<Cfg, INV, P>(v, t, lds);
-        sync();
+        fft_sync<Cfg>(sync);
         run_passes<Cfg, INV, P + 1, false>(v, t, lds, tw, sync);
     }
 }

@@ -20,7 +20,15 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 #define RL_TABLE_FN RL_CAT(table_, RL_CFG_L)
 
 struct DevSync {
-    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+    __device__ __forceinline__ void wg() const { __syncthreads(); }
+    // One wave exchanging data with itself through LDS: the hardware completes a
+    // wave's LDS operations in issue order, so only compiler reordering has to be
+    // prevented (wavefront-scope fences emit no instructions).
+    __device__ __forceinline__ void wave() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 };
 
 // NOTE: the transform length is a template parameter of the kernels so that the
@@ -30,14 +38,18 @@ template <int L, int C, typename T>
 __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C) k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    colconv_body<typename CfgFor<L>::Cfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    using KCfg = typename CfgFor<L>::Cfg;
+    if constexpr (WavePrivate<KCfg>::value)
+        colconv_wave_body<KCfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    else
+        colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 
-template <int L, int Q, int MODE, typename T>
+template <int L, int Q, int MODE, bool ONEV, typename T>
 __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q) k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    rowpass_body<typename CfgFor<L>::Cfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    rowpass_body<typename CfgFor<L>::Cfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 
 template <int C, typename T>
@@ -55,7 +67,11 @@ static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hip
 template <int Q, int MODE, typename T>
 static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
-    k_rowpass<RL_CFG_L, Q, MODE, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
+    constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
+    if (MULTI && p.V == 1)   // single view: variant without accumulator registers
+        k_rowpass<RL_CFG_L, Q, MODE, MULTI, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
+    else
+        k_rowpass<RL_CFG_L, Q, MODE, false, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
     return hipGetLastError();
 }
 
@@ -91,11 +107,13 @@ template <int Q, typename T>
 static hipError_t prepare_rows() {
     hipError_t e;
     const size_t b = lds_bytes<Q, T>();
-    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_FWD, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_INV, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_RATIO, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, T>, b)) != hipSuccess) return e;
-    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_FWD, false, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_INV, false, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_RATIO, false, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, false, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, true, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, false, T>, b)) != hipSuccess) return e;
+    if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, true, T>, b)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -109,7 +127,8 @@ static hipError_t prepare() {
 }
 
 const KernelTable* RL_TABLE_FN() {
-    static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, launch_col, launch_row, prepare};
+    static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, WavePrivate<Cfg>::value ? 1 : 0,
+                                  launch_col, launch_row, prepare};
     return &t;
 }
 

@@ -13,6 +13,7 @@ struct KernelTable {
     int T;            // threads per transform
     int C[2];         // spectrum columns per workgroup in the column kernel, per dtype
     int Q[2];         // row pairs per workgroup in the row kernels, per dtype
+    int psf_transposed;   // column kernel reads psf_hat as [view][Kx][L] (wave-private transforms)
     // params: pointer to ColParams<T> / RowParams<T> of the matching dtype
     hipError_t (*launch_col)(int dtype, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);
     hipError_t (*launch_row)(int dtype, int mode, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);

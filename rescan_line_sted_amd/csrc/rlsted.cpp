@@ -355,7 +355,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         HIP_TRY(hipMalloc(&s1, V * h->py * h->kx * 16));
         HIP_TRY(hipMemcpyAsync(psf_dev, psfs, np * 8, hipMemcpyHostToDevice, ctx->stream));
         hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat, h->V, h->py, h->px,
-                                        h->ly, h->lx, h->kx, h->pitch, ctx->stream);
+                                        h->ly, h->lx, h->kx, h->pitch, h->ty->psf_transposed, ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
         hipFree(psf_dev);
         hipFree(s1);

@@ -19,8 +19,10 @@
 using namespace rl;
 
 struct EmuSync {
-    pthread_barrier_t* bar;
-    void operator()() const { pthread_barrier_wait(bar); }
+    pthread_barrier_t* bar;        // whole workgroup
+    pthread_barrier_t* wave_bar;   // the 64 threads of this thread's wavefront
+    void wg() const { pthread_barrier_wait(bar); }
+    void wave() const { pthread_barrier_wait(wave_bar); }
 };
 
 template <class Body>
@@ -28,6 +30,12 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
     std::vector<unsigned char> lds(lds_bytes + 64);
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, nullptr, nthreads);
+    const int nwaves = (nthreads + 63) / 64;
+    std::vector<pthread_barrier_t> wbar(nwaves);
+    for (int w = 0; w < nwaves; ++w) {
+        const int n = (w + 1) * 64 <= nthreads ? 64 : nthreads - w * 64;
+        pthread_barrier_init(&wbar[w], nullptr, n);
+    }
     for (int by = 0; by < gy; ++by)
         for (int bx = 0; bx < gx; ++bx) {
             std::memset(lds.data(), 0xff, lds.size());   // poison: NaNs if read before written
@@ -35,12 +43,13 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
             th.reserve(nthreads);
             for (int tid = 0; tid < nthreads; ++tid)
                 th.emplace_back([&, tid]() {
-                    EmuSync s{&bar};
+                    EmuSync s{&bar, &wbar[tid / 64]};
                     body(tid, bx, by, lds.data(), s);
                 });
             for (auto& t : th) t.join();
         }
     pthread_barrier_destroy(&bar);
+    for (auto& b : wbar) pthread_barrier_destroy(&b);
 }
 
 template <typename T>
@@ -68,7 +77,10 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
     run_grid((kx + C - 1) / C, frames * V, Cfg::T * C, (size_t)C * LdsLen<L>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
-                 colconv_body<Cfg, C, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 if constexpr (WavePrivate<Cfg>::value)
+                     colconv_wave_body<Cfg, C, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 else
+                     colconv_body<Cfg, C, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
              });
     return 0;
 }
@@ -81,7 +93,11 @@ static int row_m(const RowParams<T>& p, int gy) {
     const int pairs = (p.ny + 1) / 2;
     run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsLen<L>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
-                 rowpass_body<Cfg, Q, MODE, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
+                 if (MULTI && p.V == 1)   // same dispatch as launch_row_m in fft_kernels.hip
+                     rowpass_body<Cfg, Q, MODE, MULTI, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 else
+                     rowpass_body<Cfg, Q, MODE, false, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
              });
     return 0;
 }
@@ -116,8 +132,9 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
 
 extern "C" {
 
+// returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
-#define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return 0;
+#define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return WavePrivate<CfgFor<LL>::Cfg>::value ? 1 : 0;
     switch (L) { GEO(64) GEO(192) GEO(256) GEO(576) GEO(1152) GEO(2304) }
     return -2;
 }

@@ -57,7 +57,16 @@ class EmuPlan:
             xx = (np.arange(Px) - cx) % Lx
             w[np.ix_(yy, xx)] = p[0]
             ph[v, :, :self.kx] = np.fft.rfft2(w) / (Ly * Lx)
-        self.psf_hat = ph
+        self.psf_hat_natural = ph
+        t, c, q = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.transposed = lib.emu_geometry(Ly, ctypes.byref(t), ctypes.byref(c), ctypes.byref(q))
+        assert self.transposed in (0, 1)
+        if self.transposed:      # [view][kx][Ly], as the device plan stores it for wave-private lengths
+            pht = np.zeros((self.V, Ly, self.pitch), dtype=self.ct).reshape(-1)
+            pht[:self.V * self.kx * Ly] = np.ascontiguousarray(ph[:, :, :self.kx].transpose(0, 2, 1)).reshape(-1)
+            self.psf_hat = pht
+        else:
+            self.psf_hat = ph
 
     def row(self, mode, gy, spec_in=None, spec_out=None, src=None, dst=None,
             norm=None, scale=None):
@@ -141,7 +150,7 @@ def test_column_pass_is_circular_convolution_along_y(emu):
             for v in range(pl.V):
                 pad = np.zeros((Ly, pl.kx), dtype=complex)
                 pad[:ny] = sin[b, :, :pl.kx]
-                ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat[v, :, :pl.kx], axis=0)[:ny] * Ly
+                ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat_natural[v, :, :pl.kx], axis=0)[:ny] * Ly
                 assert max_rel(sout[b * pl.V + v, :, :pl.kx], ref) < 1e-13
         # H_t indexing, in place
         s2 = pl.spec(B * pl.V)
@@ -151,7 +160,7 @@ def test_column_pass_is_circular_convolution_along_y(emu):
         for i in range(B * pl.V):
             pad = np.zeros((Ly, pl.kx), dtype=complex)
             pad[:ny] = keep[i, :, :pl.kx]
-            ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat[i % pl.V, :, :pl.kx], axis=0)[:ny] * Ly
+            ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat_natural[i % pl.V, :, :pl.kx], axis=0)[:ny] * Ly
             assert max_rel(s2[i, :, :pl.kx], ref) < 1e-13
 
 
@@ -159,6 +168,8 @@ def test_column_pass_is_circular_convolution_along_y(emu):
     (40, 48, 64, 64, [(1, 9, 11)]),
     (33, 31, 64, 64, [(1, 7, 7), (1, 8, 10), (1, 1, 7)]),    # odd sizes, even PSF, 3 views
     (128, 128, 192, 192, [(1, 107, 107)]),
+    (24, 530, 64, 576, [(1, 5, 47)]),        # the 576 row transforms (wave private, radix 9-8-8)
+    (530, 6, 576, 64, [(1, 47, 3)]),         # the 576 column transforms
 ])
 def test_forward_model_matches_oracle(emu, ny, nx, Ly, Lx, pshapes):
     rng = np.random.default_rng(3)
