@@ -101,6 +101,40 @@ int rl_deconv_last_ms(const rl_deconv* h, double* iterate_ms, double* simulate_m
  * measured with hipEvents on the plan's stream.                              */
 int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t seed, double* total_ms);
 
+/* ---- PSF generation: line_sted_tools.py:75-363, 653-668 ---------------------
+ * get_width (:653-668): MINPACK-lmdif fit of A*exp(-(x-mu)^2/(2 sigma^2)) to
+ * y[0..n-1] from [1, n/2, 1] with scipy.optimize.curve_fit's defaults; host
+ * code, needs no GPU.  p3 = {A, mu, sigma}; *info = MINPACK info (may be NULL). */
+int rl_gauss_fit(const double* y, int n, double* p3, int* info);
+
+/* scipy.ndimage.gaussian_filter as the reference uses it (:185-213,260,280):
+ * float64, mode 'reflect', radius int(truncate*sigma+0.5), axes with sigma <=
+ * 1e-15 skipped.  in/out: host [nz][ny][nx].                                   */
+int rl_gaussian_filter(rl_ctx* ctx, const double* in, double* out, int nz, int ny, int nx,
+                       const double* sigma3, double truncate);
+
+/* generate_psfs (:168-363) for shape (1, ny, nx).  psf_type 0 = 'point', 1 =
+ * 'line'.  rescan_ratio > 0 forces the integer line rescan ratio, <= 0 derives
+ * it from the fitted width of the central sted row (:252-256).
+ * arrays_out: NULL or [5 (point) | 7 (line)][ny][nx] = excitation, depletion,
+ *   excitation_fraction, depletion_fraction, sted, descan_sted, rescan_sted.
+ * rows_out:   NULL or [3][nx] central rows of excitation, sted, rescan_sted.
+ * scalars_out[10]: 0 ratio used, 1 ideal ratio, 2-4 area sums of excitation /
+ *   depletion / sted, 5-7 central-row sums of the same, 8 = 1 when every
+ *   central-row maximum equals its array maximum (asserts :105-106,120).      */
+int rl_psf_generate(rl_ctx* ctx, int psf_type, int ny, int nx, double excitation_brightness,
+                    double depletion_brightness, double blur_sigma, int rescan_ratio,
+                    double* arrays_out, double* rows_out, double* scalars_out);
+
+/* psf_report (:75-166).  report_out[8] = { resolution_improvement_descanned,
+ * resolution_improvement_rescanned (NaN for 'point'), excitation_dose,
+ * depletion_dose, expected_emission, num_steps n, line rescan ratio, invariant
+ * flag as scalars_out[8] above }.  arrays_out as in rl_psf_generate with ny = nx
+ * = n = 1 + 2*round(5*sigma) (NULL: scalars only).                             */
+int rl_psf_report(rl_ctx* ctx, int psf_type, double excitation_brightness, double depletion_brightness,
+                  double steps_per_excitation_psf_width, double pulses_per_position,
+                  double* arrays_out, double* report_out);
+
 /* Per-kernel device time: launches each kernel of the RL iteration `reps`
  * times back to back between two hipEvents on the plan's stream and returns
  * the average milliseconds per launch in avg_ms[6] = { column pass (H),

@@ -44,6 +44,10 @@ PROTOTYPES = {
     'rl_deconv_last_ms': (_i, [_vp, _dp, _dp]),
     'rl_deconv_bench_cycles': (_i, [_vp, _i, _i, _i, _c.c_uint64, _dp]),
     'rl_deconv_time_kernels': (_i, [_vp, _i, _dp]),
+    'rl_gauss_fit': (_i, [_dp, _i, _dp, _c.POINTER(_i)]),
+    'rl_gaussian_filter': (_i, [_vp, _dp, _dp, _i, _i, _i, _dp, _c.c_double]),
+    'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
+    'rl_psf_report': (_i, [_vp, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _dp, _dp]),
 }
 
 

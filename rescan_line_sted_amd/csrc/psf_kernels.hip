@@ -1,0 +1,201 @@
+// psf_kernels.hip -- gfx950 kernels for PSF generation, float64.
+//
+// Reference: figure_generation/line_sted_tools.py generate_psfs (:168-363).
+// PSFs are tiny ((1,n,n), n <= ~133) so these kernels are latency bound; the
+// point is that the whole psf_report pipeline stays on the device between the
+// two host-side Gaussian fits, with float64 arithmetic in the reference's
+// operation order (exact-equality asserts :105-106,120 depend on symmetry).
+#include <hip/hip_runtime.h>
+#include "psf_kernels.hpp"
+
+namespace rl {
+
+// half-sample symmetric extension (scipy 'reflect'): d c b a | a b c d | d c b a
+__device__ __forceinline__ int reflect_index(int i, int n) {
+    const int period = 2 * n;
+    int m = i % period;
+    if (m < 0) m += period;
+    return m >= n ? period - 1 - m : m;
+}
+
+// scipy.ndimage correlate1d, symmetric-kernel branch (call sites :185-213,260,280):
+// out[i] = x[i]*w[r] + sum_{j=-r}^{-1} (x[i+j] + x[i-j]) * w[r+j], outermost pair first.
+__global__ void k_blur_axis(const double* __restrict__ in, double* __restrict__ out, int nz, int ny, int nx, int axis,
+                            const double* __restrict__ w, int radius) {
+    const int total = nz * ny * nx;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int x = e % nx, y = (e / nx) % ny, z = e / (nx * ny);
+    const int len = axis == 0 ? nz : (axis == 1 ? ny : nx);
+    const int pos = axis == 0 ? z : (axis == 1 ? y : x);
+    const int stride = axis == 0 ? ny * nx : (axis == 1 ? nx : 1);
+    const double* line = in + (e - pos * stride);
+    double acc = line[pos * stride] * w[radius];
+    for (int j = -radius; j < 0; ++j) {
+        const double a = line[reflect_index(pos + j, len) * stride];
+        const double b = line[reflect_index(pos - j, len) * stride];
+        acc += (a + b) * w[radius + j];
+    }
+    out[e] = acc;
+}
+
+// delta at the centre pixel (kind 0, :183-184) or a one-pixel vertical line (kind 1, :189-190)
+__global__ void k_delta(double* out, int ny, int nx, int kind) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const int x = e % nx, y = e / nx;
+    out[e] = (x == nx / 2 && (kind == 1 || y == ny / 2)) ? 1.0 : 0.0;
+}
+
+// Single-workgroup reduction with wavefront shuffles; op 0 = max, 1 = sum.
+// `stride`/`count` select a strided slice (a whole array or one row).
+__global__ void __launch_bounds__(1024) k_reduce(const double* __restrict__ in, int count, int stride, int op,
+                                                 double* __restrict__ out) {
+    __shared__ double part[16];
+    double v = op == 0 ? -1.0e308 : 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const double x = in[(size_t)i * stride];
+        v = op == 0 ? (x > v ? x : v) : v + x;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(v, off, 64);
+        v = op == 0 ? (o > v ? o : v) : v + o;
+    }
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = (blockDim.x + 63) / 64;
+        v = lane < nw ? part[lane] : (op == 0 ? -1.0e308 : 0.0);
+        for (int off = 8; off > 0; off >>= 1) {
+            const double o = __shfl_down(v, off, 64);
+            v = op == 0 ? (o > v ? o : v) : v + o;
+        }
+        if (lane == 0) *out = v;
+    }
+}
+
+// exc = g * (exc_b / max g); dep_raw = outer/max(outer) - g/max(g)      (:187,204-206)
+__global__ void k_psf_stage1(const double* __restrict__ g, const double* __restrict__ outer, const double* __restrict__ maxes,
+                             double exc_b, double* __restrict__ exc, double* __restrict__ dep_raw, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double mg = maxes[0], mo = maxes[1];
+    exc[e] = g[e] * (exc_b / mg);
+    dep_raw[e] = (outer[e] / mo) - (g[e] / mg);
+}
+
+// dep = dep_raw * (dep_b / max dep_raw); fractions; sted                 (:207,226-240)
+__global__ void k_psf_stage2(const double* __restrict__ exc, double* __restrict__ dep, const double* __restrict__ maxes,
+                             double dep_b, double* __restrict__ exc_frac, double* __restrict__ dep_frac,
+                             double* __restrict__ sted, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double d = dep[e] * (dep_b / maxes[2]);
+    dep[e] = d;
+    const double ef = 1.0 - exp2(-exc[e] / 1.0);
+    const double df = exp2(-d / 1.0);
+    exc_frac[e] = ef;
+    dep_frac[e] = df;
+    sted[e] = ef * df;
+}
+
+// ---- rescan simulation, :258-310 -------------------------------------------
+// The object is a centred delta, so at scan position sp the glow is the single
+// value a = sted_row[(2cx - sp) mod nx] at the centre pixel and the blurred glow
+// is ((b0[sp] * ry[y]) * rx[x]) with b0 the axis-0 pass of the 3-axis blur.
+__device__ __forceinline__ int wrap(int i, int n) {
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+__global__ void k_rescan_b0(const double* __restrict__ sted_row, const double* __restrict__ w, int radius, int n,
+                            double* __restrict__ b0) {
+    const int sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sp >= n) return;
+    const double a = sted_row[wrap(2 * (n / 2) - sp, n)];
+    double acc = a * w[radius];                      // axis 0 has length 1: every tap reads the same value
+    for (int j = -radius; j < 0; ++j) acc += (a + a) * w[radius + j];
+    b0[sp] = acc;
+}
+
+// blurred_sp[y][x] for the glow at scan position sp.  ry / rx are the responses of
+// the 1-D blur (with its reflect boundary) to a unit impulse at the centre
+// row / column; without boundary contact they are just the Gaussian weights.
+__device__ __forceinline__ double blurred(const double* b0, const double* ry, const double* rx, int sp, int y, int x) {
+    return (b0[sp] * ry[y]) * rx[x];
+}
+
+// descanned_signal_cumu[y][sp] = sum_x roll(blurred_sp, c - sp)[y][x]       (:285-288)
+__global__ void k_descan(const double* __restrict__ b0, const double* __restrict__ ry, const double* __restrict__ rx,
+                         int ny, int nx, double* __restrict__ descan) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const int sp = e % nx, y = e / nx, c = nx / 2;
+    double acc = 0.0;
+    for (int x = 0; x < nx; ++x) acc += blurred(b0, ry, rx, sp, y, wrap(x - (c - sp), nx));
+    descan[e] = acc;
+}
+
+// rescanned_signal_cumu[y][X], X < ratio*nx: sum over sp (in order) of the
+// instantaneous image rolled to sp*ratio - c in the ratio*nx ring           (:291-298)
+__global__ void k_rescan_cumu(const double* __restrict__ b0, const double* __restrict__ ry, const double* __restrict__ rx,
+                              int ny, int nx, int ratio, double* __restrict__ cumu) {
+    const int rn = ratio * nx;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * rn) return;
+    const int X = e % rn, y = e / rn, c = nx / 2;
+    double acc = 0.0;
+    for (int sp = 0; sp < nx; ++sp) {
+        const int xp = wrap(X - (sp * ratio - c), rn);       // column of the un-rolled instantaneous image
+        if (xp < nx) acc += blurred(b0, ry, rx, sp, y, wrap(xp - (c - sp), nx));
+    }
+    cumu[e] = acc;
+}
+
+// rescan[y][j] = sum_q roll(cumu, ratio/2)[y][j*ratio + q]                   (:301-309)
+__global__ void k_rescan_bin(const double* __restrict__ cumu, int ny, int nx, int ratio, double* __restrict__ rescan) {
+    const int rn = ratio * nx;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const int j = e % nx, y = e / nx;
+    double acc = 0.0;
+    for (int q = 0; q < ratio; ++q) acc += cumu[(size_t)y * rn + wrap(j * ratio + q - ratio / 2, rn)];
+    rescan[e] = acc;
+}
+
+static inline unsigned nblk(int n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t psf_blur_axis(const double* in, double* out, int nz, int ny, int nx, int axis, const double* w, int radius,
+                         hipStream_t s) {
+    k_blur_axis<<<nblk(nz * ny * nx), 256, 0, s>>>(in, out, nz, ny, nx, axis, w, radius);
+    return hipGetLastError();
+}
+hipError_t psf_delta(double* out, int ny, int nx, int kind, hipStream_t s) {
+    k_delta<<<nblk(ny * nx), 256, 0, s>>>(out, ny, nx, kind);
+    return hipGetLastError();
+}
+hipError_t psf_reduce(const double* in, int count, int stride, int op, double* out, hipStream_t s) {
+    k_reduce<<<1, 1024, 0, s>>>(in, count, stride, op, out);
+    return hipGetLastError();
+}
+hipError_t psf_stage1(const double* g, const double* outer, const double* maxes, double exc_b, double* exc,
+                      double* dep_raw, int n, hipStream_t s) {
+    k_psf_stage1<<<nblk(n), 256, 0, s>>>(g, outer, maxes, exc_b, exc, dep_raw, n);
+    return hipGetLastError();
+}
+hipError_t psf_stage2(const double* exc, double* dep, const double* maxes, double dep_b, double* exc_frac,
+                      double* dep_frac, double* sted, int n, hipStream_t s) {
+    k_psf_stage2<<<nblk(n), 256, 0, s>>>(exc, dep, maxes, dep_b, exc_frac, dep_frac, sted, n);
+    return hipGetLastError();
+}
+hipError_t psf_rescan(const double* sted_row, const double* w, int radius, const double* ry, const double* rx, int ny,
+                      int nx, int ratio, double* b0, double* cumu, double* descan, double* rescan, hipStream_t s) {
+    k_rescan_b0<<<nblk(nx), 256, 0, s>>>(sted_row, w, radius, nx, b0);
+    k_descan<<<nblk(ny * nx), 256, 0, s>>>(b0, ry, rx, ny, nx, descan);
+    k_rescan_cumu<<<nblk(ny * ratio * nx), 256, 0, s>>>(b0, ry, rx, ny, nx, ratio, cumu);
+    k_rescan_bin<<<nblk(ny * nx), 256, 0, s>>>(cumu, ny, nx, ratio, rescan);
+    return hipGetLastError();
+}
+
+}  // namespace rl

@@ -17,30 +17,26 @@
 #include "aux_kernels.hpp"
 #include "conv_kernels.hpp"
 #include "kernel_table.hpp"
+#include "ctx.hpp"
 
 using namespace rl;
 
-namespace {
-
-thread_local std::string g_err;
-const bool g_debug_sync = getenv("RLSTED_DEBUG_SYNC") != nullptr;   // sync + check after every launch
-
+namespace rl {
+std::string& last_error() {
+    thread_local std::string e;
+    return e;
+}
 int fail(int code, const std::string& msg) {
-    g_err = msg;
+    last_error() = msg;
     return code;
 }
+bool debug_sync() {
+    static const bool v = getenv("RLSTED_DEBUG_SYNC") != nullptr;
+    return v;
+}
+}  // namespace rl
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
-    } while (0)
-#define RL_TRY(expr)            \
-    do {                        \
-        int r_ = (expr);        \
-        if (r_ != RL_OK) return r_; \
-    } while (0)
+namespace {
 
 const KernelTable* table_for(int L) {
     switch (L) {
@@ -57,54 +53,7 @@ const int kLengths[] = {64, 192, 256, 576, 1152, 2304};
 
 size_t esize(int dtype) { return dtype == RL_F32 ? 4 : 8; }
 
-struct Twiddles {
-    void* t = nullptr;     // complex of plan dtype
-    void* d = nullptr;     // complex128 (PSF spectrum)
-};
-
 }  // namespace
-
-struct rl_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::map<std::pair<int, int>, void*> tw;   // (L, dtype) -> device table
-    std::map<int, bool> prepared;
-
-    int twiddles(int L, int dtype, void** out) {
-        auto key = std::make_pair(L, dtype);
-        auto it = tw.find(key);
-        if (it != tw.end()) {
-            *out = it->second;
-            return RL_OK;
-        }
-        std::vector<double> h(2 * (size_t)L);
-        for (int m = 0; m < L; ++m) {
-            // exact octant symmetry is not needed: long double cos/sin of the reduced angle
-            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)L;
-            h[2 * m] = (double)cosl(a);
-            h[2 * m + 1] = (double)sinl(a);
-        }
-        void* dev = nullptr;
-        if (dtype == RL_F64) {
-            HIP_TRY(hipMalloc(&dev, sizeof(double) * 2 * L));
-            HIP_TRY(hipMemcpy(dev, h.data(), sizeof(double) * 2 * L, hipMemcpyHostToDevice));
-        } else {
-            std::vector<float> f(h.begin(), h.end());
-            HIP_TRY(hipMalloc(&dev, sizeof(float) * 2 * L));
-            HIP_TRY(hipMemcpy(dev, f.data(), sizeof(float) * 2 * L, hipMemcpyHostToDevice));
-        }
-        tw[key] = dev;
-        *out = dev;
-        return RL_OK;
-    }
-
-    int prepare(const KernelTable* t) {
-        if (prepared[t->L]) return RL_OK;
-        HIP_TRY(t->prepare());
-        prepared[t->L] = true;
-        return RL_OK;
-    }
-};
 
 struct rl_deconv {
     rl_ctx* ctx = nullptr;
@@ -156,7 +105,7 @@ struct rl_deconv {
             auto p = colp<double>(in, out, h_mode);
             HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
         }
-        if (g_debug_sync) {
+        if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess)
                 return fail(RL_ERR_HIP, "column kernel L=" + std::to_string(ly) + " grid " + std::to_string(gx) + "x" +
@@ -179,7 +128,7 @@ struct rl_deconv {
         const int Q = tx->Q[dtype];
         const unsigned pairs = (unsigned)((ny + 1) / 2);
         HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
-        if (g_debug_sync) {
+        if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess)
                 return fail(RL_ERR_HIP, "row kernel mode " + std::to_string(mode) + " L=" + std::to_string(lx) + " grid " +
@@ -247,7 +196,7 @@ struct rl_deconv {
 
 extern "C" {
 
-const char* rl_last_error(void) { return g_err.c_str(); }
+const char* rl_last_error(void) { return rl::last_error().c_str(); }
 int rl_version(void) { return 100; }
 
 int rl_device_count(int* count) {
@@ -290,6 +239,7 @@ int rl_ctx_destroy(rl_ctx* c) {
     if (!c) return RL_OK;
     hipSetDevice(c->device);
     for (auto& kv : c->tw) hipFree(kv.second);
+    if (c->psf_work) hipFree(c->psf_work);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return RL_OK;
@@ -390,9 +340,9 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
     int r = deconv_build(h, psfs);
     if (r != RL_OK) {
-        std::string keep = g_err;
+        std::string keep = rl::last_error();
         rl_deconv_destroy(h);
-        g_err = keep;
+        rl::last_error() = keep;
         return r;
     }
     *out = h;

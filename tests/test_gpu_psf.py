@@ -1,0 +1,138 @@
+"""PSF half of the path on the GPU: psf_report / generate_psfs / tune_psf /
+gaussian_filter / get_width of the mirror module against golden vectors from the
+reference and against the CPU oracle.  float64 on the device.
+
+Tolerances: PSF arrays 1e-12 normwise (same arithmetic, same operation order);
+fitted widths 1e-8 (the MINPACK iteration is restated, exp() rounding differs);
+tune_psf 1e-6 (Brent amplifies rounding-level differences of its objective).
+"""
+import numpy as np
+import pytest
+
+from conftest import max_rel
+from oracle import line_sted_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def st():
+    from rescan_line_sted_amd import line_sted_tools
+    return line_sted_tools
+
+
+def _parse(key):
+    t, s, e, d, p = key.split('_')
+    return t, float(s[1:]), float(e[1:]), float(d[1:]), int(p[1:])
+
+
+def test_g1_psf_report_matches_reference(st, golden):
+    g = golden('g1_psf_report')
+    for key in g['cases']:
+        key = str(key)
+        psf_type, steps, exc, dep, pulses = _parse(key)
+        r = st.psf_report(psf_type, exc, dep, steps, pulses, verbose=False)
+        sc = g[key + '/scalars']
+        want_keys = {'resolution_improvement_descanned', 'excitation_dose', 'depletion_dose',
+                     'expected_emission', 'pulses_per_position', 'psfs'}
+        if psf_type == 'line':
+            want_keys.add('resolution_improvement_rescanned')
+        assert set(r.keys()) == want_keys
+        assert r['resolution_improvement_descanned'] == pytest.approx(sc[0], rel=1e-8)
+        if psf_type == 'line':
+            assert r['resolution_improvement_rescanned'] == pytest.approx(sc[1], rel=1e-8)
+        assert r['excitation_dose'] == pytest.approx(sc[2], rel=1e-12)
+        assert r['depletion_dose'] == pytest.approx(sc[3], rel=1e-12, abs=1e-300)
+        assert r['expected_emission'] == pytest.approx(sc[4], rel=1e-12)
+        assert r['pulses_per_position'] == pulses
+        if pulses != 1:
+            continue
+        n = r['psfs']['sted'].shape[1]
+        assert set(r['psfs'].keys()) == ({'excitation', 'depletion', 'excitation_fraction', 'depletion_fraction',
+                                          'sted', 'descan_sted'} | ({'rescan_sted'} if psf_type == 'line' else set()))
+        if psf_type == 'point':
+            assert r['psfs']['descan_sted'] is r['psfs']['sted']       # alias, ref:249
+        for k, v in r['psfs'].items():
+            assert v.shape == (1, n, n) and v.dtype == np.float64
+            if key + '/psf/' + k in g:
+                assert max_rel(v, g[key + '/psf/' + k]) < 1e-12, (key, k)
+            else:
+                assert max_rel(v[0, n // 2, :], g[key + '/row/' + k]) < 1e-12, (key, k)
+                assert max_rel(v[0, :, n // 2], g[key + '/col/' + k]) < 1e-12, (key, k)
+        # the reference's exact-equality invariants hold on the device result
+        assert r['psfs']['sted'][0, n // 2, :].max() == r['psfs']['sted'].max()
+        assert r['psfs']['excitation'][0, n // 2, :].max() == r['psfs']['excitation'].max()
+
+
+def test_generate_psfs_general_shapes_vs_oracle(st):
+    # non-square shapes, and shapes small enough for the 'reflect' boundary to matter
+    for shape, sigma in (((1, 31, 45), 3.0), ((1, 44, 30), 2.2), ((1, 9, 9), 2.5), ((1, 15, 21), 4.0)):
+        for psf_type in ('point', 'line'):
+            got = st.generate_psfs(shape, 0.7, 5.0, sigma, psf_type, verbose=False)
+            ref = orc.generate_psfs(shape, 0.7, 5.0, sigma, psf_type)
+            ref.pop('line_rescan_ratio', None)
+            assert set(got) == set(ref)
+            for k in ref:
+                assert max_rel(got[k], ref[k]) < 1e-12, (shape, psf_type, k)
+
+
+def test_gaussian_filter_vs_oracle():
+    from rescan_line_sted_amd import psf
+    rng = np.random.default_rng(3)
+    a = rng.random((3, 17, 23))
+    for sigma in (1.7, (0, 0, 2.5), (0.8, 3.1, 0.0), 6.0):
+        assert max_rel(psf.gaussian_filter(a, sigma), orc.gaussian_filter(a, sigma)) < 1e-13
+
+
+def test_get_width(st, golden):
+    g = golden('g2_get_width')
+    for row, fit, (n, w) in zip(g['rows'], g['fits'], g['n_and_width']):
+        n = int(n)
+        s, f = st.get_width(row[:n])
+        assert abs(s) == pytest.approx(abs(w), rel=1e-8)
+        assert max_rel(f, fit[:n]) < 1e-7
+
+
+@pytest.mark.parametrize('name,which', [('1p5x_ld', 'point'), ('2p0x_lr', 'point'), ('1p5x_lr', 'line'),
+                                        ('1p0x_ld', 'line'), ('2p0x_lr', 'line')])
+def test_g3_tune_psf_matches_reference(st, golden, name, which):
+    g = golden('g3_tune_psf')
+    pr, lr, pe, le, nori, maxexc, resc = g[name + '/inputs']
+    if which == 'point':
+        r = st.tune_psf('point', 'descanned', float(pr), float(pe),
+                        max_excitation_brightness=float(maxexc), steps_per_improved_psf_width=4.)
+    else:
+        r = st.tune_psf('line', 'rescanned' if resc else 'descanned', float(lr), float(le),
+                        max_excitation_brightness=float(maxexc), steps_per_improved_psf_width=4.)
+    ref = dict(zip([str(k) for k in g['keys']], g[name + '/' + which]))
+    for k in ('excitation_brightness', 'depletion_brightness', 'pulses_per_position',
+              'steps_per_excitation_psf_width', 'excitation_dose', 'depletion_dose',
+              'expected_emission', 'resolution_improvement_descanned'):
+        assert r[k] == pytest.approx(ref[k], rel=1e-6, abs=1e-9), k
+    assert 'psfs' in r and r['psf_type'] == which and r['verbose'] is False
+    import pickle
+    pickle.loads(pickle.dumps(r))            # line_sted_figure_2.py:165 pickles these dicts
+
+
+def test_fig2_psf_set_feeds_the_deconvolver(st, golden, tmp_path):
+    """psf_comparison_pair's point branch (line_sted_figure_2.py:220-238) rebuilt from
+    the mirror module reproduces the golden fig-2 PSF."""
+    g = golden('g8_fig2_psfs')
+    keys = ('excitation_brightness', 'depletion_brightness', 'pulses_per_position')
+    point = dict(zip(keys, g['2p0x_lr/point'][:3]))
+    fine = st.psf_report('point', point['excitation_brightness'], point['depletion_brightness'], 25,
+                         point['pulses_per_position'], verbose=False)
+    emission = g['2p0x_lr/point'][6]
+    psf = emission * fine['psfs']['descan_sted'] / fine['psfs']['descan_sted'].sum()
+    assert max_rel(psf, g['2p0x_lr/point_sted_psf'][0]) < 1e-12
+
+
+def test_error_behaviour(st):
+    with pytest.raises(AssertionError):
+        st.tune_psf('point', 'rescanned', 1.5, 4.0)          # ref:398-400
+    with pytest.raises(AssertionError):
+        st.Deconvolver([np.ones((1, 3, 3))], verbose=False).create_data_from_object(
+            np.ones((4, 4)))                                  # ref:502
+    with pytest.raises(AssertionError):
+        st.Deconvolver([np.ones((1, 3, 3))], verbose=False).create_data_from_object(
+            np.ones((1, 4, 4), dtype=np.float32))             # ref:503

@@ -103,3 +103,36 @@ def test_g9_logarithmic_progress(golden):
     g = golden('g9_progress')
     for n in (0, 1, 2, 3, 5, 17, 1025):
         assert list(g['n%d' % n]) == orc.logarithmic_progress_flags(n)
+
+
+@pytest.mark.parametrize('name,which', [('1p5x_ld', 'point'), ('1p5x_lr', 'line'), ('1p0x_ld', 'line')])
+def test_g3_tune_psf(golden, name, which):
+    """tune_psf at fig-2 operating points (inputs: line_sted_figure_2.py:77-162).
+    The Brent search amplifies rounding-level differences of its objective, so
+    agreement is ~1e-8, not 1e-12."""
+    g = golden('g3_tune_psf')
+    pr, lr, pe, le, nori, maxexc, resc = g[name + '/inputs']
+    if which == 'point':
+        r = orc.tune_psf('point', 'descanned', float(pr), float(pe),
+                         max_excitation_brightness=maxexc, steps_per_improved_psf_width=4.)
+    else:
+        r = orc.tune_psf('line', 'rescanned' if resc else 'descanned', float(lr), float(le),
+                         max_excitation_brightness=maxexc, steps_per_improved_psf_width=4.)
+    ref = dict(zip([str(k) for k in g['keys']], g[name + '/' + which]))
+    for k in ('excitation_brightness', 'depletion_brightness', 'pulses_per_position',
+              'excitation_dose', 'depletion_dose', 'expected_emission',
+              'resolution_improvement_descanned'):
+        assert r[k] == pytest.approx(ref[k], rel=1e-6, abs=1e-9), k
+
+
+def test_published_dose_table(golden):
+    """appendix.html:222-247 of the reference: excitation / depletion dose of the
+    six point-STED operating points (the only numbers the reference publishes)."""
+    g = golden('g3_tune_psf')
+    table = {'1p0x_ld': (5.8, 0.0), '1p5x_ld': (11.4, 500.3), '2p0x_ld': (18.8, 1696.8),
+             '2p5x_ld': (30.3, 4159.5), '3p0x_ld': (46.7, 8601.8), '4p0x_ld': (90.7, 27044.0)}
+    keys = [str(k) for k in g['keys']]
+    for name, (exc, dep) in table.items():
+        ref = dict(zip(keys, g[name + '/point']))
+        assert abs(ref['excitation_dose'] - exc) < 0.06
+        assert abs(ref['depletion_dose'] - dep) < 0.06
