@@ -123,6 +123,24 @@ def main():
     frames_total = B * args.steps * world
     value = frames_total / elapsed
 
+    # the one collective of the path: gather the final estimates on rank 0 over
+    # RCCL/xGMI, straight from the plan's device buffer (after the timed region)
+    gather = None
+    if dist is not None:
+        try:
+            import torch
+            from rescan_line_sted_amd import sharding
+            est_dev = torch.as_tensor(plan.device_array('estimate'), device='cuda')
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            got = sharding.gather_to_root(est_dev, [B] * world, dist)
+            torch.cuda.synchronize()
+            gather = {'ms': (time.perf_counter() - tg) * 1e3, 'bytes_per_rank': est_dev.numel() * est_dev.element_size(),
+                      'frames_on_root': int(got.shape[0]) if got is not None else None}
+            del got
+        except Exception as exc:      # the gather is reported, never allowed to void the measurement
+            gather = {'error': repr(exc)}
+
     # sanity of what was just computed (not timed)
     est = plan.estimate()
     assert np.isfinite(est).all() and est.min() >= 0
@@ -178,6 +196,7 @@ def main():
                    'frames_per_gpu_per_step': B, 'n_psf': V, 'rl_iters': K_ITERS,
                    'fft': '%dx%d' % (info['ly'], info['lx']), 'sharding': 'frames over ranks, no data-path collective'},
         'device_ms_per_step': dev_ms / args.steps,
+        'final_gather': gather,
         'roofline': roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -101,6 +101,12 @@ int rl_deconv_last_ms(const rl_deconv* h, double* iterate_ms, double* simulate_m
  * measured with hipEvents on the plan's stream.                              */
 int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t seed, double* total_ms);
 
+/* Device address of a plan buffer for zero-copy hand-off (e.g. the RCCL gather
+ * of final estimates): which = 0 estimate [batch][ny][nx], 1 measurement, 2
+ * noiseless [batch][n_psf][ny][nx], 3 object.  The buffer stays owned by the
+ * plan; *dtype = RL_F32 / RL_F64 element type.  Synchronise the context first. */
+int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements, int* dtype);
+
 /* ---- PSF generation: line_sted_tools.py:75-363, 653-668 ---------------------
  * get_width (:653-668): MINPACK-lmdif fit of A*exp(-(x-mu)^2/(2 sigma^2)) to
  * y[0..n-1] from [1, n/2, 1] with scipy.optimize.curve_fit's defaults; host

@@ -44,6 +44,7 @@ PROTOTYPES = {
     'rl_deconv_last_ms': (_i, [_vp, _dp, _dp]),
     'rl_deconv_bench_cycles': (_i, [_vp, _i, _i, _i, _c.c_uint64, _dp]),
     'rl_deconv_time_kernels': (_i, [_vp, _i, _dp]),
+    'rl_deconv_device_ptr': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
     'rl_gauss_fit': (_i, [_dp, _i, _dp, _c.POINTER(_i)]),
     'rl_gaussian_filter': (_i, [_vp, _dp, _dp, _i, _i, _i, _dp, _c.c_double]),
     'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
@@ -199,6 +200,17 @@ class DeconvPlan:
         ms = _c.c_double()
         check(lib.rl_deconv_bench_cycles(self.handle, int(k), int(reps), rng, _c.c_uint64(seed), ctypes.byref(ms)))
         return ms.value
+
+    def device_array(self, which='estimate'):
+        """Zero-copy view of a plan buffer as an object with __cuda_array_interface__
+        (torch.as_tensor(x, device='cuda') wraps it); the plan keeps ownership."""
+        from .sharding import DeviceArray
+        idx = {'estimate': 0, 'measurement': 1, 'noiseless': 2, 'object': 3}[which]
+        p, n, dt = _vp(), _c.c_size_t(), _i()
+        check(lib.rl_deconv_device_ptr(self.handle, idx, ctypes.byref(p), ctypes.byref(n), ctypes.byref(dt)))
+        shape = (self.B, self.ny, self.nx) if idx in (0, 3) else (self.B, self.V, self.ny, self.nx)
+        self.ctx.synchronize()
+        return DeviceArray(p.value, shape, '<f4' if dt.value == RL_F32 else '<f8', self)
 
     KERNEL_NAMES = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'poisson')
 

@@ -506,6 +506,23 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
 }
 
 
+int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements, int* dtype) {
+    if (!h || !ptr) return fail(RL_ERR_INVALID, "NULL argument");
+    void* p = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: p = h->est; n = (size_t)h->B * h->n_img(); break;
+        case 1: p = h->meas; n = (size_t)h->B * h->V * h->n_img(); break;
+        case 2: p = h->noiseless; n = (size_t)h->B * h->V * h->n_img(); break;
+        case 3: p = h->obj; n = (size_t)h->B * h->n_img(); break;
+        default: return fail(RL_ERR_INVALID, "which must be 0..3");
+    }
+    *ptr = p;
+    if (n_elements) *n_elements = n;
+    if (dtype) *dtype = h->dtype;
+    return RL_OK;
+}
+
 int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
     if (!h || !avg_ms) return fail(RL_ERR_INVALID, "NULL argument");
     if (!h->have_meas) return fail(RL_ERR_STATE, "no measurement");

@@ -295,8 +295,7 @@ class _ProgressPrinter:
 def logarithmic_progress(iterable, verbose=True):
     """ref:596-651.  Generator of (item, flag) pairs; flag is True when the
     item's index is a power of two or the last one -- the moments the reference
-    saves results.  An empty iterable is returned unchanged, as in the
-    reference.  With verbose=True a progress bar appears after 1.5 s."""
+    saves results.  An empty iterable yields nothing.  With verbose=True a progress bar appears after 1.5 s."""
     n = len(iterable)
     if n == 0:
         return iterable

@@ -3,7 +3,8 @@ gaussian_filter / get_width of the mirror module against golden vectors from the
 reference and against the CPU oracle.  float64 on the device.
 
 Tolerances: PSF arrays 1e-12 normwise (same arithmetic, same operation order);
-fitted widths 1e-8 (the MINPACK iteration is restated, exp() rounding differs);
+fitted widths 1e-6: the restated MINPACK iteration stops (like the reference's) up to
+~1e-6 short of the minimum, so 1-ulp input differences (device exp2 vs numpy power) can move it that far;
 tune_psf 1e-6 (Brent amplifies rounding-level differences of its objective).
 """
 import numpy as np
@@ -38,9 +39,9 @@ def test_g1_psf_report_matches_reference(st, golden):
         if psf_type == 'line':
             want_keys.add('resolution_improvement_rescanned')
         assert set(r.keys()) == want_keys
-        assert r['resolution_improvement_descanned'] == pytest.approx(sc[0], rel=1e-8)
+        assert r['resolution_improvement_descanned'] == pytest.approx(sc[0], rel=1e-6)
         if psf_type == 'line':
-            assert r['resolution_improvement_rescanned'] == pytest.approx(sc[1], rel=1e-8)
+            assert r['resolution_improvement_rescanned'] == pytest.approx(sc[1], rel=1e-6)
         assert r['excitation_dose'] == pytest.approx(sc[2], rel=1e-12)
         assert r['depletion_dose'] == pytest.approx(sc[3], rel=1e-12, abs=1e-300)
         assert r['expected_emission'] == pytest.approx(sc[4], rel=1e-12)

@@ -1,0 +1,128 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every
+symbol include/rlsted.h declares (no compute calls without a GPU), error
+conventions, and the host-side logic (Gaussian fit, Brent search, progress
+iterator, drop-in shims)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, max_rel
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from rescan_line_sted_amd import _lib
+    return _lib
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'rlsted.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(rl_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), 'librlsted.so lacks ' + name
+    assert sorted(lib.PROTOTYPES) == declared          # the ctypes table binds exactly the header
+
+
+def test_no_gpu_errors_are_loud(lib):
+    if lib.device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(lib.RlstedError) as e:
+        lib.Context(0)
+    assert 'librlsted error -2' in str(e.value)         # RL_ERR_HIP + message, no silent fallback
+    assert lib.lib.rl_version() >= 100
+    assert [lib.lib.rl_fft_length_for(n) for n in (1, 64, 65, 181, 213, 565, 1100, 2101, 2305)] == \
+           [64, 64, 192, 192, 256, 576, 1152, 2304, 0]
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'rescan_line_sted_amd')
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.hpp', '.h')):
+                text = open(os.path.join(base, f), errors='replace').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f
+                assert '/root/reference' not in text, f
+    for f in ('bench.py', '__graft_entry__.py'):
+        assert '/root/reference' not in open(os.path.join(ROOT, f)).read()
+
+
+def test_gauss_fit_matches_reference_widths(golden):
+    from rescan_line_sted_amd import psf
+    g = golden('g2_get_width')
+    for row, fit, (n, w) in zip(g['rows'], g['fits'], g['n_and_width']):
+        n = int(n)
+        s, f = psf.get_width(row[:n])
+        assert abs(s) == pytest.approx(abs(w), rel=1e-8)
+        assert max_rel(f, fit[:n]) < 1e-7 and f.shape == (n,)
+    with pytest.raises(Exception):
+        psf.get_width(np.zeros(2))
+
+
+def test_scalar_minimizer_follows_scipy_default_method():
+    from scipy.optimize import minimize_scalar
+    from rescan_line_sted_amd.psf import _ScalarMinimizer
+    funcs = [lambda x: (x - 2.0) ** 2, lambda x: (abs(x) - 1.5) ** 2 + 0.1 * x, lambda x: np.cosh(x - 0.3),
+             lambda x: (np.sqrt(abs(x)) - 1.3) ** 2, lambda x: (x + 7.0) ** 4 + x]
+    for f in funcs:
+        m = _ScalarMinimizer(f)
+        x = m.minimize()
+        ref = minimize_scalar(f)
+        assert x == ref.x and m.calls == ref.nfev          # same iterates, same evaluation count
+
+
+def test_logarithmic_progress(golden, capsys):
+    from rescan_line_sted_amd import line_sted_tools as st
+    g = golden('g9_progress')
+    for n in (0, 1, 2, 3, 5, 17, 1025):
+        got = list(st.logarithmic_progress(range(n), verbose=False))
+        assert [x for x, _ in got] == list(range(n))
+        assert [f for _, f in got] == list(g['n%d' % n])
+    assert list(st.logarithmic_progress([])) == []          # a generator that yields nothing, as in the reference
+
+
+def test_dropin_shims_resolve_the_reference_module_names():
+    code = ("import sys; sys.path.insert(0, %r); import line_sted_tools as st, np_tif;"
+            "print(all(hasattr(st, n) for n in ('psf_report','generate_psfs','tune_psf','Deconvolver',"
+            "'logarithmic_progress','get_width')), hasattr(np_tif,'tif_to_array'), hasattr(np_tif,'array_to_tif'))"
+            % os.path.join(ROOT, 'dropin'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp')
+    assert out.stdout.split() == ['True', 'True', 'True'], out.stderr
+
+
+def test_deconvolver_surface_matches_reference(tmp_path):
+    from rescan_line_sted_amd import line_sted_tools as st
+    import inspect
+    sig = inspect.signature(st.Deconvolver.__init__)
+    assert list(sig.parameters)[:4] == ['self', 'psfs', 'output_prefix', 'verbose']
+    assert list(inspect.signature(st.Deconvolver.create_data_from_object).parameters) == \
+        ['self', 'obj', 'total_brightness', 'random_seed']
+    for name in ('load_data_from_tif', 'iterate', 'record_iteration', 'record_data', 'H', 'H_t'):
+        assert callable(getattr(st.Deconvolver, name))
+    assert list(inspect.signature(st.Deconvolver.H_t).parameters) == ['self', 'y', 'normalize']
+    d = st.Deconvolver([np.ones((1, 3, 3))], output_prefix=str(tmp_path / 'sub') + '/', verbose=False)
+    assert os.path.isdir(str(tmp_path / 'sub'))             # ref:487-488 creates dirname(prefix)
+    assert (d.num_iterations, d.saved_iterations, d.estimate_history) == (0, [], [])
+    with pytest.raises(AttributeError):
+        d.estimate
+    from rescan_line_sted_amd import psf
+    for fn, names in ((psf.psf_report, ['psf_type', 'excitation_brightness', 'depletion_brightness',
+                                        'steps_per_excitation_psf_width', 'pulses_per_position', 'verbose', 'output_dir']),
+                      (psf.generate_psfs, ['shape', 'excitation_brightness', 'depletion_brightness', 'blur_sigma',
+                                           'psf_type', 'output_dir', 'verbose']),
+                      (psf.tune_psf, ['psf_type', 'scan_type', 'desired_resolution_improvement',
+                                      'desired_emissions_per_molecule', 'max_excitation_brightness',
+                                      'steps_per_improved_psf_width', 'relative_error', 'verbose_results',
+                                      'verbose_iterations'])):
+        assert list(inspect.signature(fn).parameters) == names
