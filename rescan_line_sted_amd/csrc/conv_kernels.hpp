@@ -208,6 +208,28 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     cx<T> v[VMAX];
     cx<T> acc[(MODE == ROW_UPDATE || MODE == ROW_ADJ) && !ONEV ? NB * R : 1];
 
+    // Operands of the pointwise stage are requested before the inverse transform
+    // starts, so their HBM latency hides behind it (measurement for ROW_RATIO, the
+    // current estimate for ROW_UPDATE).
+    constexpr bool PREFETCH = (MODE == ROW_RATIO || MODE == ROW_UPDATE);
+    cx<T> pre[PREFETCH ? NB * R : 1];
+    if constexpr (PREFETCH) {
+        const T* __restrict__ src = (MODE == ROW_RATIO ? p.src : p.dst) + (size_t)by * rimg;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int j = t + nb * TT;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = j + r * NBF;
+                const bool inx = (j < NBF) && (i < p.nx);
+                cx<T> m = mk<T>((T)0, (T)0);
+                if (inx && ok0) m.re = src[(size_t)r0 * p.nx + i];
+                if (inx && ok1) m.im = src[(size_t)r1 * p.nx + i];
+                pre[nb * R + r] = m;
+            }
+        }
+    }
+
     if constexpr (MODE != ROW_FWD) {
         constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
         const int nview = (MULTI && !ONEV) ? p.V : 1;
@@ -259,20 +281,19 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (inx && ok0) dst[(size_t)r0 * p.nx + i] = v[s].re > (T)0 ? v[s].re : (T)0;
                 if (inx && ok1) dst[(size_t)r1 * p.nx + i] = v[s].im > (T)0 ? v[s].im : (T)0;
             } else if constexpr (MODE == ROW_RATIO) {
-                const T* __restrict__ meas = p.src + (size_t)by * rimg;
-                if (inx && ok0) z.re = meas[(size_t)r0 * p.nx + i] / (v[s].re > (T)0 ? v[s].re : (T)0);
-                if (inx && ok1) z.im = meas[(size_t)r1 * p.nx + i] / (v[s].im > (T)0 ? v[s].im : (T)0);
+                if (inx && ok0) z.re = pre[PREFETCH ? s : 0].re / (v[s].re > (T)0 ? v[s].re : (T)0);
+                if (inx && ok1) z.im = pre[PREFETCH ? s : 0].im / (v[s].im > (T)0 ? v[s].im : (T)0);
             } else if constexpr (MODE == ROW_UPDATE) {
                 T* __restrict__ est = p.dst + (size_t)by * rimg;
                 const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    z.re = est[o] * (a.re / p.norm[o]);
+                    z.re = pre[PREFETCH ? s : 0].re * (a.re / p.norm[o]);
                     est[o] = z.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    z.im = est[o] * (a.im / p.norm[o]);
+                    z.im = pre[PREFETCH ? s : 0].im * (a.im / p.norm[o]);
                     est[o] = z.im;
                 }
             } else if constexpr (MODE == ROW_ADJ) {

@@ -53,8 +53,9 @@ struct rl_ctx {
     std::map<std::pair<int, int>, void*> tw;   // (L, dtype) -> device table
     std::map<int, bool> prepared;
 
-    int twiddles(int L, int dtype, void** out) {
-        auto key = std::make_pair(L, dtype);
+    // plain table exp(-2 pi i m / L), float64 (PSF spectrum DFT)
+    int plain_twiddles(int L, void** out) {
+        auto key = std::make_pair(-L, (int)RL_F64);
         auto it = tw.find(key);
         if (it != tw.end()) {
             *out = it->second;
@@ -62,19 +63,37 @@ struct rl_ctx {
         }
         std::vector<double> h(2 * (size_t)L);
         for (int m = 0; m < L; ++m) {
-            // exact octant symmetry is not needed: long double cos/sin of the reduced angle
             const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)L;
             h[2 * m] = (double)cosl(a);
             h[2 * m + 1] = (double)sinl(a);
         }
         void* dev = nullptr;
+        HIP_TRY(hipMalloc(&dev, sizeof(double) * 2 * L));
+        HIP_TRY(hipMemcpy(dev, h.data(), sizeof(double) * 2 * L, hipMemcpyHostToDevice));
+        tw[key] = dev;
+        *out = dev;
+        return RL_OK;
+    }
+
+    // per-pass twiddle table of one transform length (layout: fft_core.hpp PassTw)
+    int twiddles(const rl::KernelTable* t, int dtype, void** out) {
+        auto key = std::make_pair(t->L, dtype);
+        auto it = tw.find(key);
+        if (it != tw.end()) {
+            *out = it->second;
+            return RL_OK;
+        }
+        const size_t n = 2 * (size_t)(t->tw_count > 0 ? t->tw_count : 1);
+        std::vector<double> h(n, 0.0);
+        if (t->tw_count > 0) t->fill_tw(h.data());
+        void* dev = nullptr;
         if (dtype == RL_F64) {
-            HIP_TRY(hipMalloc(&dev, sizeof(double) * 2 * L));
-            HIP_TRY(hipMemcpy(dev, h.data(), sizeof(double) * 2 * L, hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&dev, sizeof(double) * n));
+            HIP_TRY(hipMemcpy(dev, h.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         } else {
             std::vector<float> f(h.begin(), h.end());
-            HIP_TRY(hipMalloc(&dev, sizeof(float) * 2 * L));
-            HIP_TRY(hipMemcpy(dev, f.data(), sizeof(float) * 2 * L, hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&dev, sizeof(float) * n));
+            HIP_TRY(hipMemcpy(dev, f.data(), sizeof(float) * n, hipMemcpyHostToDevice));
         }
         tw[key] = dev;
         *out = dev;

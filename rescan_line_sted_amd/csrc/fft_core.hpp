@@ -197,6 +197,60 @@ struct LdsView {
     RL_HD cx<T>& at(int idx) const { return base[lds_pad(idx) * CS]; }
 };
 
+// ---------------------------------------------------------------------------
+// Inter-pass twiddles.  One table per transform length, laid out so that the
+// lanes of a wave read consecutive entries:
+//   [direction][pass P >= 1][r - 1][j]   = exp(-+ 2 pi i * r * (j mod Ns) / (Ns * R))
+// (j = butterfly index of the pass, direction 0 = forward, 1 = inverse).  The
+// table is a few KB and stays in L1/L2.
+// ---------------------------------------------------------------------------
+template <class Cfg, bool INV, int P>
+struct PassTw {
+    static constexpr int block(bool inv, int p) {   // entries of (inv, p)
+        const int r = Cfg::radix(inv ? Cfg::NP - 1 - p : p);
+        return p == 0 ? 0 : (r - 1) * (Cfg::L / r);
+    }
+    static constexpr int offset_() {
+        int o = 0;
+        for (int d = 0; d < 2; ++d)
+            for (int p = 0; p < Cfg::NP; ++p) {
+                if (d == (INV ? 1 : 0) && p == P) return o;
+                o += block(d == 1, p);
+            }
+        return o;
+    }
+    static constexpr int OFFSET = offset_();
+    static constexpr int total_() {
+        int o = 0;
+        for (int d = 0; d < 2; ++d)
+            for (int p = 0; p < Cfg::NP; ++p) o += block(d == 1, p);
+        return o;
+    }
+    static constexpr int TOTAL = total_();
+};
+
+// Host-side generator of that table (interleaved re, im doubles, 2*TOTAL values).
+template <class Cfg, bool INV, int P>
+inline void fill_pass_twiddles_one(double* out) {
+    using PI = PassInfo<Cfg, INV, P>;
+    if constexpr (P > 0) {
+        double* dst = out + 2 * PassTw<Cfg, INV, P>::OFFSET;
+        for (int r = 1; r < PI::R; ++r)
+            for (int j = 0; j < PI::NBF; ++j) {
+                const long double num = (long double)r * (long double)(j % PI::NS);
+                const long double ang = 6.283185307179586476925286766559005768L * num / (long double)(PI::NS * PI::R);
+                dst[2 * ((r - 1) * PI::NBF + j)] = (double)__builtin_cosl(ang);
+                dst[2 * ((r - 1) * PI::NBF + j) + 1] = (double)(INV ? __builtin_sinl(ang) : -__builtin_sinl(ang));
+            }
+    }
+    if constexpr (P + 1 < Cfg::NP) fill_pass_twiddles_one<Cfg, INV, P + 1>(out);
+}
+template <class Cfg>
+inline void fill_pass_twiddles(double* out) {
+    fill_pass_twiddles_one<Cfg, false, 0>(out);
+    fill_pass_twiddles_one<Cfg, true, 0>(out);
+}
+
 template <class Cfg, bool INV, int P, typename T>
 RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
     using PI = PassInfo<Cfg, INV, P>;
@@ -206,13 +260,9 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
             if constexpr (PI::NS > 1) {
-                const int base = (j % PI::NS) * (Cfg::L / (PI::NS * R));
+                const cx<T>* __restrict__ w = tw + PassTw<Cfg, INV, P>::OFFSET + j;
 #pragma unroll
-                for (int r = 1; r < R; ++r) {
-                    cx<T> w = tw[r * base];
-                    if (INV) w.im = -w.im;
-                    v[nb * R + r] = cmul(v[nb * R + r], w);
-                }
+                for (int r = 1; r < R; ++r) v[nb * R + r] = cmul(v[nb * R + r], w[(r - 1) * PI::NBF]);
             }
             dft<R, INV>(&v[nb * R]);
         }

@@ -128,7 +128,7 @@ static hipError_t prepare() {
 
 const KernelTable* RL_TABLE_FN() {
     static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, WavePrivate<Cfg>::value ? 1 : 0,
-                                  launch_col, launch_row, prepare};
+                                  PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>, launch_col, launch_row, prepare};
     return &t;
 }
 

@@ -278,8 +278,8 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     h->pitch = (h->kx + 7) / 8 * 8;
     RL_TRY(ctx->prepare(h->ty));
     RL_TRY(ctx->prepare(h->tx));
-    RL_TRY(ctx->twiddles(h->ly, h->dtype, &h->twy));
-    RL_TRY(ctx->twiddles(h->lx, h->dtype, &h->twx));
+    RL_TRY(ctx->twiddles(h->ty, h->dtype, &h->twy));
+    RL_TRY(ctx->twiddles(h->tx, h->dtype, &h->twx));
     const size_t es = esize(h->dtype), B = (size_t)h->B, V = (size_t)h->V;
     struct Req { void** p; size_t n; };
     const Req reqs[] = {
@@ -298,8 +298,8 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     // PSF spectra: direct DFT of the (py x px) support in float64 on the device
     {
         void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
-        RL_TRY(ctx->twiddles(h->ly, RL_F64, &wy));
-        RL_TRY(ctx->twiddles(h->lx, RL_F64, &wx));
+        RL_TRY(ctx->plain_twiddles(h->ly, &wy));
+        RL_TRY(ctx->plain_twiddles(h->lx, &wx));
         const size_t np = V * h->py * h->px;
         HIP_TRY(hipMalloc(&psf_dev, np * 8));
         HIP_TRY(hipMalloc(&s1, V * h->py * h->kx * 16));

@@ -52,13 +52,14 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
     for (auto& b : wbar) pthread_barrier_destroy(&b);
 }
 
-template <typename T>
-static std::vector<cx<T>> twiddles(int L) {
-    std::vector<cx<T>> tw(L);
-    for (int m = 0; m < L; ++m) {
-        long double a = -2.0L * 3.14159265358979323846264338327950288L * m / L;
-        tw[m] = mk<T>((T)cosl(a), (T)sinl(a));
-    }
+template <int L, typename T>
+static std::vector<cx<T>> twiddles() {   // the per-pass table the device plan uploads
+    using Cfg = typename CfgFor<L>::Cfg;
+    constexpr int n = PassTw<Cfg, false, 0>::TOTAL;
+    std::vector<double> h(2 * (size_t)(n > 0 ? n : 1), 0.0);
+    if (n > 0) fill_pass_twiddles<Cfg>(h.data());
+    std::vector<cx<T>> tw(n > 0 ? n : 1);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = mk<T>((T)h[2 * i], (T)h[2 * i + 1]);
     return tw;
 }
 
@@ -68,7 +69,7 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     using CF = CfgFor<L>;
     using Cfg = typename CF::Cfg;
     constexpr int C = sizeof(T) == 4 ? CF::C32 : CF::C64;
-    auto tw = twiddles<T>(L);
+    auto tw = twiddles<L, T>();
     ColParams<T> p;
     p.in = reinterpret_cast<const cx<T>*>(in);
     p.out = reinterpret_cast<cx<T>*>(out);
@@ -105,7 +106,7 @@ static int row_m(const RowParams<T>& p, int gy) {
 template <int L, typename T>
 static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, const T* scale,
                  int ny, int nx, int pitch, int V, int gy) {
-    auto tw = twiddles<T>(L);
+    auto tw = twiddles<L, T>();
     RowParams<T> p;
     p.spec_in = reinterpret_cast<const cx<T>*>(spec_in);
     p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
