@@ -24,6 +24,18 @@
 
 namespace rl {
 
+// a / b.  float: hardware reciprocal (v_rcp_f32, <= 1 ulp) times a -- the f32 plans
+// are specified to 1e-5, an IEEE-exact quotient costs ~10 instructions per element;
+// double: exact division.  On the host (emulator) both are plain divisions.
+RL_HD float rl_div(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+RL_HD double rl_div(double a, double b) { return a / b; }
+
 // ------------------------------ column pass --------------------------------
 // For one tile of C spectrum columns: forward FFT along y (rows >= ny are
 // zero), multiply by psf_hat, inverse FFT along y, keep rows < ny.
@@ -117,12 +129,24 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
     cx<T>* __restrict__ out = p.out + (size_t)by * img;
 
-    // 1. cooperative tile load (c fastest across lanes), zero fill rows >= ny
-    for (int e = tid; e < L * C; e += NT) {
-        const int row = e / C, c = e % C;
-        cx<T> x = mk<T>((T)0, (T)0);
-        if (row < p.ny && col0 + c < p.kx) x = in[(size_t)row * p.pitch + col0 + c];
-        lds[c * LP + lds_pad(row)] = x;
+    // 1. cooperative tile load (c fastest across lanes), zero fill rows >= ny.
+    //    All global loads are issued before the first LDS write (one latency, not NLD).
+    static_assert((L * C) % NT == 0, "tile must divide evenly over the workgroup");
+    constexpr int NLD = (L * C) / NT;
+    {
+        cx<T> x[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const int row = e / C, c = e % C;
+            x[it] = mk<T>((T)0, (T)0);
+            if (row < p.ny && col0 + c < p.kx) x[it] = in[(size_t)row * p.pitch + col0 + c];
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            lds[(e % C) * LP + lds_pad(e / C)] = x[it];
+        }
     }
     sync.wg();
 
@@ -157,9 +181,11 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     sync.wg();
 
     // 3. cooperative store of rows < ny
-    for (int e = tid; e < p.ny * C; e += NT) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int e = tid + it * NT;
         const int row = e / C, c = e % C;
-        if (col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+        if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
     }
 }
 
@@ -242,12 +268,24 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             const cx<T>* __restrict__ sp = p.spec_in + im * simg;
             fft_sync<Cfg>(sync);   // LDS free
             // pack the two half spectra into one Hermitian-free complex row
-            for (int k = t; k <= L / 2; k += TT) {
-                cx<T> A = mk<T>((T)0, (T)0), B = mk<T>((T)0, (T)0);
-                if (ok0) A = sp[(size_t)r0 * p.pitch + k];
-                if (ok1) B = sp[(size_t)r1 * p.pitch + k];
-                view_lds.at(k) = mk<T>(A.re - B.im, A.im + B.re);
-                if (k > 0 && k < L / 2) view_lds.at(L - k) = mk<T>(A.re + B.im, B.re - A.im);
+            // (all global loads first, then the LDS writes)
+            constexpr int NPK = (L / 2 + TT) / TT;          // ceil((L/2 + 1) / TT)
+            cx<T> A[NPK], B[NPK];
+#pragma unroll
+            for (int it = 0; it < NPK; ++it) {
+                const int k = t + it * TT;
+                A[it] = mk<T>((T)0, (T)0);
+                B[it] = mk<T>((T)0, (T)0);
+                if (k <= L / 2 && ok0) A[it] = sp[(size_t)r0 * p.pitch + k];
+                if (k <= L / 2 && ok1) B[it] = sp[(size_t)r1 * p.pitch + k];
+            }
+#pragma unroll
+            for (int it = 0; it < NPK; ++it) {
+                const int k = t + it * TT;
+                if (k <= L / 2) {
+                    view_lds.at(k) = mk<T>(A[it].re - B[it].im, A[it].im + B[it].re);
+                    if (k > 0 && k < L / 2) view_lds.at(L - k) = mk<T>(A[it].re + B[it].im, B[it].re - A[it].im);
+                }
             }
             fft_sync<Cfg>(sync);
             run_passes<Cfg, true, 0, false>(v, t, view_lds, p.tw, sync);
@@ -281,19 +319,19 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (inx && ok0) dst[(size_t)r0 * p.nx + i] = v[s].re > (T)0 ? v[s].re : (T)0;
                 if (inx && ok1) dst[(size_t)r1 * p.nx + i] = v[s].im > (T)0 ? v[s].im : (T)0;
             } else if constexpr (MODE == ROW_RATIO) {
-                if (inx && ok0) z.re = pre[PREFETCH ? s : 0].re / (v[s].re > (T)0 ? v[s].re : (T)0);
-                if (inx && ok1) z.im = pre[PREFETCH ? s : 0].im / (v[s].im > (T)0 ? v[s].im : (T)0);
+                if (inx && ok0) z.re = rl_div(pre[PREFETCH ? s : 0].re, v[s].re > (T)0 ? v[s].re : (T)0);
+                if (inx && ok1) z.im = rl_div(pre[PREFETCH ? s : 0].im, v[s].im > (T)0 ? v[s].im : (T)0);
             } else if constexpr (MODE == ROW_UPDATE) {
                 T* __restrict__ est = p.dst + (size_t)by * rimg;
                 const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    z.re = pre[PREFETCH ? s : 0].re * (a.re / p.norm[o]);
+                    z.re = pre[PREFETCH ? s : 0].re * rl_div(a.re, p.norm[o]);
                     est[o] = z.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    z.im = pre[PREFETCH ? s : 0].im * (a.im / p.norm[o]);
+                    z.im = pre[PREFETCH ? s : 0].im * rl_div(a.im, p.norm[o]);
                     est[o] = z.im;
                 }
             } else if constexpr (MODE == ROW_ADJ) {
@@ -327,10 +365,15 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         }
         fft_sync<Cfg>(sync);
         cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg;
-        for (int k = t; k <= L / 2; k += TT) {
-            const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
-            if (ok0) so[(size_t)r0 * p.pitch + k] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
-            if (ok1) so[(size_t)r1 * p.pitch + k] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+        constexpr int NUP = (L / 2 + TT) / TT;
+#pragma unroll
+        for (int it = 0; it < NUP; ++it) {
+            const int k = t + it * TT;
+            if (k <= L / 2) {
+                const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
+                if (ok0) so[(size_t)r0 * p.pitch + k] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
+                if (ok1) so[(size_t)r1 * p.pitch + k] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+            }
         }
     }
 }

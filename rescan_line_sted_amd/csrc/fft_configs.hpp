@@ -37,7 +37,7 @@ struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
 template <>
 struct CfgFor<1152> { // 1024 + 53
     using Cfg = FftCfg<1152, 144, 8, 9, 16>;
-    static constexpr int C32 = 4, C64 = 4, Q32 = 4, Q64 = 4;
+    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
 };
 template <>
 struct CfgFor<2304> { // 2048 + 53

@@ -153,10 +153,8 @@ RL_HD double philox_poisson(double lam, uint64_t seed, uint32_t image, uint32_t 
         return X;
     }
     const double slam = __builtin_sqrt(lam);
-    const double loglam = det_log(lam);
     const double b = 0.931 + 2.53 * slam;
     const double a = -0.059 + 0.02483 * b;
-    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
     const double vr = 0.9277 - 3.6224 / (b - 2.0);
     double k = __builtin_floor(lam);
     for (uint32_t blk = 0; blk < 64; ++blk) {
@@ -165,9 +163,12 @@ RL_HD double philox_poisson(double lam, uint64_t seed, uint32_t image, uint32_t 
         const double V = u53(o.x[2], o.x[3]);
         const double us = 0.5 - (U < 0.0 ? -U : U);
         k = __builtin_floor((2.0 * a / us + b) * U + lam + 0.43);
-        if (us >= 0.07 && V <= vr) return k;
+        if (us >= 0.07 && V <= vr) return k;                     // ~87 % of pixels leave here
         if (k < 0.0 || (us < 0.013 && V > us)) continue;
         if (!(V > 0.0)) return k;
+        // slow path: the logarithms are evaluated only here (same values as if hoisted)
+        const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+        const double loglam = det_log(lam);
         const double lhs = (det_log(V) + det_log(invalpha)) - det_log(a / (us * us) + b);
         const double rhs = (k * loglam - lam) - det_logfact(k);
         if (lhs <= rhs) return k;
