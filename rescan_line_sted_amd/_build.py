@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'librlsted.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-FFT_LENGTHS = (64, 192, 256, 576, 1152, 2304)
+FFT_LENGTHS = (64, 192, 256, 576, 1152, 2304, 4608)
 COMMON = ['-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include')]
 DEVICE = ['--offload-arch=' + ARCH, '-munsafe-fp-atomics']
 

@@ -45,4 +45,10 @@ struct CfgFor<2304> { // 2048 + 53
     static constexpr int C32 = 4, C64 = 2, Q32 = 2, Q64 = 2;
 };
 
+template <>
+struct CfgFor<4608> { // 4096 + 53: one transform per workgroup (functional support, not tuned)
+    using Cfg = FftCfg<4608, 576, 8, 8, 8, 9>;
+    static constexpr int C32 = 1, C64 = 1, Q32 = 1, Q64 = 1;
+};
+
 }  // namespace rl

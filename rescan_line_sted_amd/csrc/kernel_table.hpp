@@ -29,5 +29,6 @@ const KernelTable* table_256();
 const KernelTable* table_576();
 const KernelTable* table_1152();
 const KernelTable* table_2304();
+const KernelTable* table_4608();
 
 }  // namespace rl

@@ -46,10 +46,11 @@ const KernelTable* table_for(int L) {
         case 576: return table_576();
         case 1152: return table_1152();
         case 2304: return table_2304();
+        case 4608: return table_4608();
     }
     return nullptr;
 }
-const int kLengths[] = {64, 192, 256, 576, 1152, 2304};
+const int kLengths[] = {64, 192, 256, 576, 1152, 2304, 4608};
 
 size_t esize(int dtype) { return dtype == RL_F32 ? 4 : 8; }
 
@@ -176,20 +177,60 @@ struct rl_deconv {
         RL_TRY(row(ROW_INV, (unsigned)(B * V), spec_b, nullptr, nullptr, noiseless, nullptr));
         return RL_OK;
     }
+    // ---- frame chunks: run the whole K-iteration loop on a slice of the batch whose
+    // working set (spectra + measurement + estimate) fits the 256 MiB Infinity Cache,
+    // so the inter-kernel traffic is served on die instead of from HBM.
+    char* off(void* base, size_t elems) const { return (char*)base + elems * esize(dtype); }
+    int chunk_frames() const {
+        static const double budget_mb = getenv("RLSTED_CHUNK_MB") ? atof(getenv("RLSTED_CHUNK_MB")) : 288.0;
+        const double per_frame = ((1.0 + V) * 2.0 * n_spec() + (1.0 + V) * n_img()) * esize(dtype);
+        int c = (int)(budget_mb * 1048576.0 / per_frame);
+        if (c < 1) c = 1;
+        if (c >= B) return B;
+        if (c > 8) c -= c % 8;
+        return c;
+    }
+    int start_estimate_chunk(int f0, int nf) {
+        HIP_TRY(aux_fill(dtype, off(est, (size_t)f0 * n_img()), (size_t)nf * n_img(), 1.0, ctx->stream));
+        RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, off(spec_a, (size_t)f0 * n_spec() * 2), off(est, (size_t)f0 * n_img()),
+                   nullptr, nullptr));
+        return RL_OK;
+    }
+    int iterate_chunk(int f0, int nf) {
+        void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
+        void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
+        RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
+        RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
+        RL_TRY(col(sb, sb, nf, false));                                                                  // H_t, column part
+        RL_TRY(row(ROW_UPDATE, (unsigned)nf, sb, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));   // est *= H_t / norm
+        return RL_OK;
+    }
     int start_estimate() {
-        HIP_TRY(aux_fill(dtype, est, (size_t)B * n_img(), 1.0, ctx->stream));
-        RL_TRY(row(ROW_FWD, (unsigned)B, nullptr, spec_a, est, nullptr, nullptr));
+        RL_TRY(start_estimate_chunk(0, B));
         est_ready = true;
         spec_valid = true;
         iterations = 0;
         return RL_OK;
     }
     int iterate_once() {
-        RL_TRY(col(spec_a, spec_b, B, true));                                              // H(est), column part
-        RL_TRY(row(ROW_RATIO, (unsigned)(B * V), spec_b, spec_b, meas, nullptr, nullptr)); // meas / H(est)
-        RL_TRY(col(spec_b, spec_b, B, false));                                             // H_t, column part
-        RL_TRY(row(ROW_UPDATE, (unsigned)B, spec_b, spec_a, nullptr, est, norm));          // est *= H_t / norm
+        RL_TRY(iterate_chunk(0, B));
         ++iterations;
+        return RL_OK;
+    }
+    // (optionally restart from est = 1 and) run k iterations, chunk by chunk
+    int run_iterations(int k, bool restart) {
+        const int cf = chunk_frames();
+        for (int f0 = 0; f0 < B; f0 += cf) {
+            const int nf = f0 + cf <= B ? cf : B - f0;
+            if (restart) RL_TRY(start_estimate_chunk(f0, nf));
+            for (int i = 0; i < k; ++i) RL_TRY(iterate_chunk(f0, nf));
+        }
+        if (restart) {
+            est_ready = true;
+            spec_valid = true;
+            iterations = 0;
+        }
+        iterations += k;
         return RL_OK;
     }
 };
@@ -271,7 +312,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     h->ly = rl_fft_length_for(h->ny + (cy_lo > cy_hi ? cy_lo : cy_hi));
     h->lx = rl_fft_length_for(h->nx + (cx_lo > cx_hi ? cx_lo : cx_hi));
     if (!h->ly || !h->lx)
-        return fail(RL_ERR_UNSUPPORTED, "image + PSF half width exceeds the largest built transform length (2304)");
+        return fail(RL_ERR_UNSUPPORTED, "image + PSF half width exceeds the largest built transform length (4608)");
     h->ty = table_for(h->ly);
     h->tx = table_for(h->lx);
     h->kx = h->lx / 2 + 1;
@@ -422,13 +463,12 @@ int rl_deconv_iterate(rl_deconv* h, int k) {
     if (!h->have_meas) return fail(RL_ERR_STATE, "no measurement: call rl_deconv_simulate or rl_deconv_set_measurement");
     HIP_TRY(hipSetDevice(h->ctx->device));
     HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
-    if (!h->est_ready) {
-        RL_TRY(h->start_estimate());
-    } else if (!h->spec_valid) {   // H / H_t were called in between: rebuild rowFFT(est)
+    bool restart = !h->est_ready;
+    if (!restart && !h->spec_valid) {   // H / H_t were called in between: rebuild rowFFT(est)
         RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->est, nullptr, nullptr));
         h->spec_valid = true;
     }
-    for (int i = 0; i < k; ++i) RL_TRY(h->iterate_once());
+    RL_TRY(h->run_iterations(k, restart));
     HIP_TRY(hipEventRecord(h->ev1, h->ctx->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0;
@@ -494,8 +534,7 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
         HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V),
                             seed + (uint64_t)r, rng_kind, s));         // noisy = Poisson(noiseless) + 1e-9
         h->have_meas = true;
-        RL_TRY(h->start_estimate());                                   // est = 1
-        for (int i = 0; i < k; ++i) RL_TRY(h->iterate_once());
+        RL_TRY(h->run_iterations(k, true));                            // est = 1, then k iterations (chunked)
     }
     HIP_TRY(hipEventRecord(h->ev1, s));
     HIP_TRY(hipEventSynchronize(h->ev1));

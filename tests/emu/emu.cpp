@@ -136,7 +136,7 @@ extern "C" {
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
 #define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return WavePrivate<CfgFor<LL>::Cfg>::value ? 1 : 0;
-    switch (L) { GEO(64) GEO(192) GEO(256) GEO(576) GEO(1152) GEO(2304) }
+    switch (L) { GEO(64) GEO(192) GEO(256) GEO(576) GEO(1152) GEO(2304) GEO(4608) }
     return -2;
 }
 

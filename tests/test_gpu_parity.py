@@ -153,6 +153,44 @@ def test_batch_of_frames_equals_frames_run_alone(lib, golden, astronaut512):
         assert np.array_equal(one.estimate()[0], est[f])      # bitwise: no cross-frame coupling
 
 
+# ------------------------------------- BASELINE configs 3 and 5: large images
+def test_2048_line_rescan_batch_vs_oracle(lib, golden):
+    """Config 3 shape: synthetic 2048x2048 random object, line-rescan (4 views), a
+    batch of noise seeds; 2 RL iterations against the oracle (a 20-iteration
+    oracle run at this size takes minutes), then flux/positivity at K = 20."""
+    psfs = [p[None] for p in golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][:, 0]]
+    obj = np.random.default_rng(1234).random((1, 2048, 2048)) * 255
+    plan = lib.DeconvPlan(psfs, 2, 2048, 2048, dtype='f32')
+    assert plan.info()['ly'] == 2304
+    plan.set_object(np.concatenate([obj, obj]), 5e10 * 256)
+    plan.simulate(seed=5)
+    noisy = plan.measurement()
+    assert not np.array_equal(noisy[0], noisy[1])                # frames draw different noise
+    d = orc.Deconvolver(psfs)
+    d.create_data_from_object(obj, 5e10 * 256, noisy_measurement=list(noisy[0][:, None]))
+    for v in range(4):
+        assert max_rel(plan.noiseless()[0, v], d.noiseless_measurement[v][0]) < 2e-6
+    plan.iterate(2)
+    d.iterate()
+    d.iterate()
+    assert max_rel(plan.estimate()[0], d.estimate[0]) < F32_TOL
+    plan.iterate(18)
+    est = plan.estimate()
+    assert np.isfinite(est).all() and est.min() >= 0
+
+
+def test_4096_tile_runs(lib, golden):
+    """Config 5 shape (4096x4096, L = 4608): H against the oracle, f32 and f64."""
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    x = np.random.default_rng(4321).random((1, 4096, 4096))
+    ref = orc.Deconvolver(psf).H(x)[0][0]
+    for dtype, tol in (('f32', 2e-6), ('f64', 1e-12)):
+        plan = lib.DeconvPlan(psf, 1, 4096, 4096, dtype=dtype)
+        assert plan.info()['lx'] == 4608
+        assert max_rel(plan.forward(x)[0, 0], ref) < tol
+        del plan
+
+
 # ---------------------------------------------- size independent properties
 @pytest.mark.parametrize('shape', [(512, 512), (500, 317), (129, 64), (2, 3)])
 def test_operator_properties(lib, golden, shape):
@@ -231,7 +269,7 @@ def test_edge_cases(lib):
     assert np.isfinite(plan.estimate()).all()
     # errors are reported, not swallowed
     with pytest.raises(lib.RlstedError):
-        lib.DeconvPlan([rng.random((1, 5, 5))], 1, 4000, 4000, dtype='f32')    # > largest built length
+        lib.DeconvPlan([rng.random((1, 5, 5))], 1, 5000, 5000, dtype='f32')    # > largest built length
     fresh = lib.DeconvPlan([rng.random((1, 5, 5))], 1, 16, 16)
     with pytest.raises(lib.RlstedError):
         fresh.iterate(1)                                                          # no measurement yet

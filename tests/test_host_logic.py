@@ -42,8 +42,8 @@ def test_no_gpu_errors_are_loud(lib):
         lib.Context(0)
     assert 'librlsted error -2' in str(e.value)         # RL_ERR_HIP + message, no silent fallback
     assert lib.lib.rl_version() >= 100
-    assert [lib.lib.rl_fft_length_for(n) for n in (1, 64, 65, 181, 213, 565, 1100, 2101, 2305)] == \
-           [64, 64, 192, 192, 256, 576, 1152, 2304, 0]
+    assert [lib.lib.rl_fft_length_for(n) for n in (1, 64, 65, 181, 213, 565, 1100, 2101, 2305, 4609)] == \
+           [64, 64, 192, 192, 256, 576, 1152, 2304, 4608, 0]
 
 
 def test_product_never_imports_the_oracle():
