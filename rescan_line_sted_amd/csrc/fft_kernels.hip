@@ -6,6 +6,9 @@
 #include "conv_kernels.hpp"
 #include "fft_configs.hpp"
 
+#ifndef RL_ROW_MIN_WAVES
+#define RL_ROW_MIN_WAVES 1
+#endif
 #ifndef RL_CFG_L
 #error "compile with -DRL_CFG_L=<length>"
 #endif
@@ -39,14 +42,28 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C) k_colconv(const ColParam
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs, so
+    // linear ids l and l+8 share an L2.  Two adjacent column tiles share every
+    // 128-B line of the spectrum rows (64 B each); giving each XCD a contiguous
+    // range of (image, tile) work items puts them on the same L2 at about the same
+    // time.  Pure speed heuristic -- any placement is correct.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
+    if (total % 8 == 0) {
+        const unsigned lin = by * gx + bx;
+        const unsigned w = (lin % 8) * (total / 8) + lin / 8;
+        bx = w % gx;
+        by = w / gx;
+    }
     if constexpr (WavePrivate<KCfg>::value)
-        colconv_wave_body<KCfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+        colconv_wave_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
-        colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+        colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
 
 template <int L, int Q, int MODE, bool ONEV, typename T>
-__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q) k_rowpass(const RowParams<T> p) {
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (sizeof(T) == 4 && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_ROW_MIN_WAVES : 1)
+    k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     rowpass_body<typename CfgFor<L>::Cfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
