@@ -65,6 +65,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
     LdsView<T, C> view_lds{lds + c};
 
     cx<T> v[VMAX];
+    cx<T> tl = mk<T>((T)0, (T)0);   // tail element (wave-private L = 576 only; unused here)
     {   // forward pass 0 operands straight from global memory
         using F0 = PassInfo<Cfg, false, 0>;
 #pragma unroll
@@ -79,7 +80,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
             }
         }
     }
-    run_passes<Cfg, false, 0, true>(v, t, view_lds, p.tw, sync);
+    run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
     {   // pointwise multiply in registers (element index of the last forward pass)
         using FL = PassInfo<Cfg, false, NP - 1>;
 #pragma unroll
@@ -92,7 +93,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
             }
         }
     }
-    run_passes<Cfg, true, 0, true>(v, t, view_lds, p.tw, sync);
+    run_passes<Cfg, true, 0, true>(v, tl, t, view_lds, p.tw, sync);
     {
         using IL = PassInfo<Cfg, true, NP - 1>;
 #pragma unroll
@@ -156,18 +157,22 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         LdsView<T, 1> view_lds{lds + w * LP};
         const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
         cx<T> v[VMAX];
-        run_passes<Cfg, false, 0, false>(v, lane, view_lds, p.tw, sync);
+        cx<T> tl = mk<T>((T)0, (T)0);
+        run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
         using FL = PassInfo<Cfg, false, NP - 1>;
 #pragma unroll
-        for (int nb = 0; nb < FL::NB; ++nb) {
+        for (int nb = 0; nb < FL::NBM; ++nb) {
             const int j = lane + nb * 64;
             if (j < FL::NBF) {
 #pragma unroll
                 for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[j + r * FL::NBF]);
             }
         }
-        run_passes<Cfg, true, 0, true>(v, lane, view_lds, p.tw, sync);
+        if constexpr (FL::TAIL)   // the tail value is output bitrev3(p) of butterfly 64 + jj
+            tl = cmul(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
+        run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
         using IL = PassInfo<Cfg, true, NP - 1>;
+        static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
         sync.wave();   // last pass' LDS reads are done before the column is overwritten
 #pragma unroll
         for (int nb = 0; nb < IL::NB; ++nb) {
@@ -229,9 +234,11 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     using IL = PassInfo<Cfg, true, NP - 1>;
     using F0 = PassInfo<Cfg, false, 0>;
     static_assert(IL::R == F0::R && IL::NB == F0::NB, "inverse must end on the forward's first radix");
+    static_assert(!F0::TAIL, "the pass that touches the images must be lane-local");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
 
     cx<T> v[VMAX];
+    cx<T> tl = mk<T>((T)0, (T)0);   // cross-lane tail element of the TAIL passes (fft_core.hpp)
     cx<T> acc[(MODE == ROW_UPDATE || MODE == ROW_ADJ) && !ONEV ? NB * R : 1];
 
     // Operands of the pointwise stage are requested before the inverse transform
@@ -288,7 +295,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 }
             }
             fft_sync<Cfg>(sync);
-            run_passes<Cfg, true, 0, false>(v, t, view_lds, p.tw, sync);
+            run_passes<Cfg, true, 0, false>(v, tl, t, view_lds, p.tw, sync);
             if constexpr (MULTI && !ONEV) {
 #pragma unroll
                 for (int s = 0; s < NB * R; ++s) {
@@ -351,12 +358,13 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     }
 
     if constexpr (MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE) {
-        run_passes<Cfg, false, 0, true>(v, t, view_lds, p.tw, sync);
+        run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
         // natural-order spectrum to LDS, then split it into the two rows' half spectra
         using FL = PassInfo<Cfg, false, NP - 1>;
         fft_sync<Cfg>(sync);
+        if constexpr (FL::TAIL) view_lds.at((64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF) = tl;
 #pragma unroll
-        for (int nb = 0; nb < FL::NB; ++nb) {
+        for (int nb = 0; nb < FL::NBM; ++nb) {
             const int j = t + nb * TT;
             if (j < FL::NBF) {
 #pragma unroll

@@ -165,6 +165,11 @@ struct PassInfo {
     static constexpr int NS = ns_();
     static constexpr int NBF = Cfg::L / R;                    // butterflies in this pass
     static constexpr int NB = (NBF + Cfg::T - 1) / Cfg::T;    // butterflies per thread
+    // Wave-private radix-8 pass with 64 + 8 butterflies (L = 576): the 8 left-over
+    // butterflies are 64 elements -- one per lane -- and are done ACROSS the lanes
+    // (tail_* below) instead of as a second, 8-lanes-active round of the pass.
+    static constexpr bool TAIL = (Cfg::T == 64 && R == 8 && NBF == 72);
+    static constexpr int NBM = TAIL ? 1 : NB;                 // rounds done lane-locally
 };
 
 template <class Cfg>
@@ -174,6 +179,7 @@ struct CfgRegs {
         for (int p = 0; p < Cfg::NP; ++p) {
             int r = Cfg::radix(p);
             int nb = (Cfg::L / r + Cfg::T - 1) / Cfg::T;
+            if (Cfg::T == 64 && r == 8 && Cfg::L / r == 72) nb = 1;   // PassInfo::TAIL
             if (nb * r > m) m = nb * r;
         }
         return m;
@@ -256,7 +262,7 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
     using PI = PassInfo<Cfg, INV, P>;
     constexpr int R = PI::R;
 #pragma unroll
-    for (int nb = 0; nb < PI::NB; ++nb) {
+    for (int nb = 0; nb < PI::NBM; ++nb) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
             if constexpr (PI::NS > 1) {
@@ -274,7 +280,7 @@ RL_HD void pass_store_lds(const cx<T>* v, int t, LdsView<T, CS> lds) {
     using PI = PassInfo<Cfg, INV, P>;
     constexpr int R = PI::R;
 #pragma unroll
-    for (int nb = 0; nb < PI::NB; ++nb) {
+    for (int nb = 0; nb < PI::NBM; ++nb) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
             const int j0 = (j / PI::NS) * (PI::NS * R) + (j % PI::NS);
@@ -289,7 +295,7 @@ RL_HD void pass_load_lds(cx<T>* v, int t, LdsView<T, CS> lds) {
     using PI = PassInfo<Cfg, INV, P>;
     constexpr int R = PI::R;
 #pragma unroll
-    for (int nb = 0; nb < PI::NB; ++nb) {
+    for (int nb = 0; nb < PI::NBM; ++nb) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
 #pragma unroll
@@ -313,20 +319,106 @@ RL_HD void fft_sync(Sync& sync) {
     else sync.wg();
 }
 
+// ---------------------------------------------------------------------------
+// Tail butterflies of a TAIL pass, across the lanes of the wave.
+// Lane l = jj + 8*p  (jj = l & 7, p = l >> 3) works on butterfly j = 64 + jj and
+// holds ONE element of it: input r = p of the 8-point DFT, i.e. transform element
+// (64 + jj) + 72*p.  The DFT runs as three radix-2 exchange stages with partners
+// l^32, l^16, l^8.
+//   DIF (natural in  -> bit-reversed out): lane p ends with output k = bitrev3(p)
+//   DIT (bit-reversed in -> natural out):  lane p starts with input k = bitrev3(p)
+// A forward DIF tail followed by an inverse DIT tail chains in registers exactly
+// like the lane-local butterflies do.
+// ---------------------------------------------------------------------------
+RL_HD int bitrev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
+
+// x *= exp(-+ 2 pi i m / 8), m = 0..3 (runtime, per lane)
+template <bool INV, typename T>
+RL_HD cx<T> mul_w8(cx<T> x, int m) {
+    const T h = (T)0.70710678118654752440084436210485;
+    cx<T> d = mk<T>(h * (x.re + (INV ? -x.im : x.im)), h * (x.im - (INV ? -x.re : x.re)));   // m = 1
+    cx<T> q = rot90<INV>(x);                                                                 // m = 2
+    cx<T> e = mk<T>(h * (q.re + (INV ? -q.im : q.im)), h * (q.im - (INV ? -q.re : q.re)));   // m = 3
+    return m == 0 ? x : (m == 1 ? d : (m == 2 ? q : e));
+}
+
+template <bool INV, bool DIT, typename T, class Sync>
+RL_HD cx<T> tail_dft8(cx<T> x, int lane, Sync& sync) {
+    const int p = lane >> 3;
+    const bool b2 = (p & 4) != 0, b1 = (p & 2) != 0, b0 = (p & 1) != 0;
+    cx<T> o;
+    if constexpr (!DIT) {
+        o = mk<T>(sync.shfl_xor(x.re, 32), sync.shfl_xor(x.im, 32));
+        x = b2 ? mul_w8<INV>(o - x, p & 3) : x + o;
+        o = mk<T>(sync.shfl_xor(x.re, 16), sync.shfl_xor(x.im, 16));
+        x = b1 ? (b0 ? rot90<INV>(o - x) : o - x) : x + o;
+        o = mk<T>(sync.shfl_xor(x.re, 8), sync.shfl_xor(x.im, 8));
+        x = b0 ? o - x : x + o;
+    } else {
+        o = mk<T>(sync.shfl_xor(x.re, 8), sync.shfl_xor(x.im, 8));
+        x = b0 ? o - x : x + o;
+        if (b1 && b0) x = rot90<INV>(x);
+        o = mk<T>(sync.shfl_xor(x.re, 16), sync.shfl_xor(x.im, 16));
+        x = b1 ? o - x : x + o;
+        if (b2) x = mul_w8<INV>(x, p & 3);
+        o = mk<T>(sync.shfl_xor(x.re, 32), sync.shfl_xor(x.im, 32));
+        x = b2 ? o - x : x + o;
+    }
+    return x;
+}
+
+// Element index (within the transform) of the tail value a lane holds, on the
+// input side (natural order: r = p) and on the output side of a DIF tail.
+template <class Cfg, bool INV, int P>
+RL_HD int tail_in_index(int lane) { return (64 + (lane & 7)) + (lane >> 3) * PassInfo<Cfg, INV, P>::NBF; }
+template <class Cfg, bool INV, int P>
+RL_HD int tail_out_index(int lane, int k) {   // Stockham scatter position of output k of butterfly 64 + jj
+    using PI = PassInfo<Cfg, INV, P>;
+    const int j = 64 + (lane & 7);
+    const int j0 = (j / PI::NS) * (PI::NS * PI::R) + (j % PI::NS);
+    return j0 + k * PI::NS;
+}
+
+// One TAIL pass for the tail element: [load] -> inter-pass twiddle -> cross-lane DFT.
+// FROM_REGS (only the chained inverse first pass): tl arrives in bit-reversed order
+// from the previous forward tail and the DIT network is used (NS == 1, no twiddle).
+template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, int CS, class Sync>
+RL_HD void tail_compute(cx<T>& tl, int lane, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
+    using PI = PassInfo<Cfg, INV, P>;
+    if constexpr (FROM_REGS) {
+        static_assert(PI::NS == 1, "a register-chained tail must be the first pass");
+        tl = tail_dft8<INV, true>(tl, lane, sync);
+    } else {
+        tl = lds.at(tail_in_index<Cfg, INV, P>(lane));
+        if constexpr (PI::NS > 1) {
+            const int r = lane >> 3, j = 64 + (lane & 7);
+            if (r > 0) tl = cmul(tl, tw[PassTw<Cfg, INV, P>::OFFSET + (r - 1) * PI::NBF + j]);
+        }
+        tl = tail_dft8<INV, false>(tl, lane, sync);
+    }
+}
+
 // Runs passes P..NP-1.  Pass P takes its input from registers when FROM_REGS,
 // otherwise from LDS (natural order).  The last pass leaves its output in
-// registers: slot nb*R + r  <->  element (t + nb*T) + r*NBF of the last pass.
+// registers: slot nb*R + r  <->  element (t + nb*T) + r*NBF of the last pass; for
+// a TAIL pass additionally `tl` <-> element tail index (64+jj) + 72*bitrev3(p).
 // Every LDS scatter is bracketed by syncs (all threads of the transform --
 // the whole workgroup unless the transform is wave private -- must call this).
 template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, int CS, class Sync>
-RL_HD void run_passes(cx<T>* v, int t, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
+RL_HD void run_passes(cx<T>* v, cx<T>& tl, int t, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
+    using PI = PassInfo<Cfg, INV, P>;
     if constexpr (!FROM_REGS) pass_load_lds<Cfg, INV, P>(v, t, lds);
+    if constexpr (PI::TAIL) tail_compute<Cfg, INV, P, FROM_REGS>(tl, t, lds, tw, sync);
     pass_compute<Cfg, INV, P>(v, t, tw);
     if constexpr (P + 1 < Cfg::NP) {
         fft_sync<Cfg>(sync);   // everyone has finished reading the previous LDS contents
         pass_store_lds<Cfg, INV, P>(v, t, lds);
+        if constexpr (PI::TAIL) {
+            const int k = FROM_REGS ? (t >> 3) : bitrev3(t >> 3);   // DIT leaves natural order, DIF bit-reversed
+            lds.at(tail_out_index<Cfg, INV, P>(t, k)) = tl;
+        }
         fft_sync<Cfg>(sync);
-        run_passes<Cfg, INV, P + 1, false>(v, t, lds, tw, sync);
+        run_passes<Cfg, INV, P + 1, false>(v, tl, t, lds, tw, sync);
     }
 }
 

@@ -32,6 +32,9 @@ struct DevSync {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // value held by lane (this lane ^ mask); all 64 lanes must be active
+    __device__ __forceinline__ float shfl_xor(float v, int mask) const { return __shfl_xor(v, mask, 64); }
+    __device__ __forceinline__ double shfl_xor(double v, int mask) const { return __shfl_xor(v, mask, 64); }
 };
 
 // NOTE: the transform length is a template parameter of the kernels so that the

@@ -21,8 +21,18 @@ using namespace rl;
 struct EmuSync {
     pthread_barrier_t* bar;        // whole workgroup
     pthread_barrier_t* wave_bar;   // the 64 threads of this thread's wavefront
+    double* xchg;                  // 64 slots shared by the wavefront (cross-lane shuffles)
+    int lane;
     void wg() const { pthread_barrier_wait(bar); }
     void wave() const { pthread_barrier_wait(wave_bar); }
+    double shfl_xor(double v, int mask) const {
+        xchg[lane] = v;
+        pthread_barrier_wait(wave_bar);
+        const double o = xchg[lane ^ mask];
+        pthread_barrier_wait(wave_bar);
+        return o;
+    }
+    float shfl_xor(float v, int mask) const { return (float)shfl_xor((double)v, mask); }
 };
 
 template <class Body>
@@ -32,6 +42,7 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
     pthread_barrier_init(&bar, nullptr, nthreads);
     const int nwaves = (nthreads + 63) / 64;
     std::vector<pthread_barrier_t> wbar(nwaves);
+    std::vector<double> xchg((size_t)nwaves * 64);
     for (int w = 0; w < nwaves; ++w) {
         const int n = (w + 1) * 64 <= nthreads ? 64 : nthreads - w * 64;
         pthread_barrier_init(&wbar[w], nullptr, n);
@@ -43,7 +54,7 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
             th.reserve(nthreads);
             for (int tid = 0; tid < nthreads; ++tid)
                 th.emplace_back([&, tid]() {
-                    EmuSync s{&bar, &wbar[tid / 64]};
+                    EmuSync s{&bar, &wbar[tid / 64], &xchg[(size_t)(tid / 64) * 64], tid % 64};
                     body(tid, bx, by, lds.data(), s);
                 });
             for (auto& t : th) t.join();
