@@ -6,8 +6,10 @@
 #include "conv_kernels.hpp"
 #include "fft_configs.hpp"
 
+// waves/SIMD requested for the f32 ROW_RATIO kernel (needs <= 96 VGPRs, which it has
+// within 2 registers; the other modes spill under that bound and are left alone)
 #ifndef RL_ROW_MIN_WAVES
-#define RL_ROW_MIN_WAVES 1
+#define RL_ROW_MIN_WAVES 5
 #endif
 #ifndef RL_CFG_L
 #error "compile with -DRL_CFG_L=<length>"
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C) k_colconv(const ColParam
 }
 
 template <int L, int Q, int MODE, bool ONEV, typename T>
-__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (sizeof(T) == 4 && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_ROW_MIN_WAVES : 1)
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (sizeof(T) == 4 && MODE == ROW_RATIO && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_ROW_MIN_WAVES : 1)
     k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
