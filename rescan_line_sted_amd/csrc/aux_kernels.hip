@@ -54,16 +54,47 @@ __global__ void k_psf_dft_cols(const double2* __restrict__ s1, const double2* __
     }
 }
 
-// noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510)
+// noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510), in two launches so that
+// the rare slow path (log / log-gamma acceptance test, further attempts) does not run
+// with 13 % of the lanes active on every wave:
+//   k_poisson_fast  every pixel: first PTRS attempt; squeeze-accepted pixels are written,
+//                   the others are appended (index only) to a work list
+//   k_poisson_slow  the listed pixels, densely packed, through the full sampler
+// Values are a function of (seed, image, pixel) only, so the list order is irrelevant.
+// Each workgroup owns a fixed segment of the work list (capacity = the pixels it
+// visits), fills it through an LDS counter and publishes the fill level in counts[].
 template <typename T>
-__global__ void k_poisson(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
-                          unsigned long long seed, int rng_kind) {
+__global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
+                               unsigned long long seed, int rng_kind, unsigned* __restrict__ list, unsigned seg_cap,
+                               unsigned* __restrict__ counts) {
+    __shared__ unsigned fill;
+    if (threadIdx.x == 0) fill = 0;
+    __syncthreads();
+    unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
     const size_t total = (size_t)n_pix * n_img;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned img = (unsigned)(i / n_pix), pix = (unsigned)(i % n_pix);
         const double lam = (double)noiseless[i];
-        const double k = rng_kind == 1 ? philox_poisson(lam, seed, img, pix) : lam;
-        noisy[i] = (T)(k + 1e-9);
+        if (rng_kind != 1) {
+            noisy[i] = (T)(lam + 1e-9);
+            continue;
+        }
+        double k;
+        if (philox_poisson_fast(lam, seed, (unsigned)(i / n_pix), (unsigned)(i % n_pix), &k)) noisy[i] = (T)(k + 1e-9);
+        else seg[atomicAdd(&fill, 1u)] = (unsigned)i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = fill;
+}
+
+template <typename T>
+__global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix,
+                               unsigned long long seed, const unsigned* __restrict__ list, unsigned seg_cap,
+                               const unsigned* __restrict__ counts) {
+    const unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
+    const unsigned n = counts[blockIdx.x];
+    for (unsigned q = threadIdx.x; q < n; q += blockDim.x) {
+        const unsigned i = seg[q];
+        noisy[i] = (T)(philox_poisson((double)noiseless[i], seed, i / n_pix, i % n_pix) + 1e-9);
     }
 }
 
@@ -91,13 +122,28 @@ hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev
 }
 
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img,
-                       unsigned long long seed, int rng_kind, hipStream_t s) {
+                       unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s) {
     const size_t total = (size_t)n_pix * n_img;
-    if (dtype == DT_F32)
-        k_poisson<float><<<blocks_for(total, 256), 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, seed, rng_kind);
-    else
-        k_poisson<double><<<blocks_for(total, 256), 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, seed, rng_kind);
+    if (total >= 0xffffffffull) return hipErrorInvalidValue;      // 32-bit work-list entries
+    const unsigned g = blocks_for(total, 256);
+    // list_ws layout: g segments of seg_cap entries (seg_cap * g <= total + g*256), then g counters
+    const unsigned seg_cap = (unsigned)((total + (size_t)g * 256 - 1) / ((size_t)g * 256)) * 256;
+    unsigned* list = (unsigned*)list_ws;
+    unsigned* counts = list + (size_t)seg_cap * g;
+    if (dtype == DT_F32) {
+        k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, seed, rng_kind, list, seg_cap, counts);
+        if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, seed, list, seg_cap, counts);
+    } else {
+        k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, seed, rng_kind, list, seg_cap, counts);
+        if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, seed, list, seg_cap, counts);
+    }
     return hipGetLastError();
+}
+
+size_t aux_poisson_workspace_bytes(size_t total_pixels) {
+    const unsigned g = blocks_for(total_pixels, 256);
+    const size_t seg_cap = (total_pixels + (size_t)g * 256 - 1) / ((size_t)g * 256) * 256;
+    return (seg_cap * g + g) * sizeof(unsigned);
 }
 
 }  // namespace rl

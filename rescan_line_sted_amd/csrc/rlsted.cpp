@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -328,7 +329,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         {&h->spec_b, B * V * h->n_spec() * 2 * es},   {&h->obj, B * h->n_img() * es},
         {&h->noiseless, B * V * h->n_img() * es},     {&h->meas, B * V * h->n_img() * es},
         {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
-        {&h->scratch, B * V * h->n_img() * es}};
+        {&h->scratch, std::max(B * V * h->n_img() * es, aux_poisson_workspace_bytes(B * V * h->n_img()))}};   // also the Poisson work list
     for (const Req& r : reqs) {
         HIP_TRY(hipMalloc(r.p, r.n));
         h->bytes += r.n;
@@ -435,7 +436,7 @@ int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed) {
     if (rng_kind != RL_RNG_NONE && rng_kind != RL_RNG_PHILOX) return fail(RL_ERR_INVALID, "unknown rng_kind");
     HIP_TRY(hipSetDevice(h->ctx->device));
     HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), seed, rng_kind,
-                        h->ctx->stream));
+                        h->scratch, h->ctx->stream));
     HIP_TRY(hipStreamSynchronize(h->ctx->stream));
     h->have_meas = true;
     h->est_ready = false;
@@ -532,7 +533,7 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     for (int r = 0; r < reps; ++r) {
         RL_TRY(h->forward_object());                                   // noiseless = H(obj)
         HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V),
-                            seed + (uint64_t)r, rng_kind, s));         // noisy = Poisson(noiseless) + 1e-9
+                            seed + (uint64_t)r, rng_kind, h->scratch, s));         // noisy = Poisson(noiseless) + 1e-9
         h->have_meas = true;
         RL_TRY(h->run_iterations(k, true));                            // est = 1, then k iterations (chunked)
     }
@@ -580,7 +581,7 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
                 case 2: RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false)); break;
                 case 3: RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_b, h->spec_a, nullptr, h->est, h->norm)); break;
                 case 4: RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->obj, nullptr, nullptr)); break;
-                case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->scratch, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 1, RL_RNG_PHILOX, s)); break;
+                case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 1, RL_RNG_PHILOX, h->scratch, s)); break;
             }
         }
         HIP_TRY(hipEventRecord(h->ev1, s));

@@ -173,6 +173,11 @@ int emu_poisson(const double* lam, int n, unsigned long long seed, unsigned imag
     for (int i = 0; i < n; ++i) out[i] = philox_poisson(lam[i], seed, image, (unsigned)i);
     return 0;
 }
+// first-attempt-only variant used by the fast Poisson kernel: flags[i] = accepted
+int emu_poisson_fast(const double* lam, int n, unsigned long long seed, unsigned image, double* out, int* flags) {
+    for (int i = 0; i < n; ++i) flags[i] = philox_poisson_fast(lam[i], seed, image, (unsigned)i, &out[i]) ? 1 : 0;
+    return 0;
+}
 void emu_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
     Philox4 o = philox4x32_10(c0, c1, c2, c3, k0, k1);
     for (int i = 0; i < 4; ++i) out[i] = o.x[i];

@@ -40,6 +40,26 @@ def test_numpy_twin_matches_sampler_header_bit_for_bit(emu, seed, image):
     assert np.all(out == np.floor(out)) and np.all(out >= 0)
 
 
+def test_fast_first_attempt_is_a_prefix_of_the_full_sampler(emu):
+    """The device draws noise in two launches (fast squeeze-accept for everyone, full
+    sampler for the rest); a pixel finished by the fast kernel must get exactly the
+    value the full sampler gives."""
+    rng = np.random.default_rng(9)
+    lam = np.concatenate([[0.0, 5.0, 10.0], 10 ** (1 + rng.random(20000) * 7)])
+    full = np.empty_like(lam)
+    fast = np.empty_like(lam)
+    flags = np.zeros(lam.size, dtype=np.int32)
+    vp = ctypes.c_void_p
+    emu.emu_poisson(lam.ctypes.data_as(vp), lam.size, ctypes.c_ulonglong(77), ctypes.c_uint(2), full.ctypes.data_as(vp))
+    emu.emu_poisson_fast(lam.ctypes.data_as(vp), lam.size, ctypes.c_ulonglong(77), ctypes.c_uint(2),
+                         fast.ctypes.data_as(vp), flags.ctypes.data_as(vp))
+    acc = flags.astype(bool)
+    assert acc[0] and not acc[1]                    # lam = 0 finished, lam < 10 deferred
+    assert 0.6 < acc[3:].mean() < 0.95              # the squeeze accepts most pixels (~79 % at large rates)
+    assert acc[3:][lam[3:] > 1e4].mean() > 0.75     # P(us >= 0.07) * P(V <= vr) ~ 0.86 * 0.92
+    assert np.array_equal(fast[acc], full[acc])
+
+
 def test_det_functions_are_accurate():
     x = 10 ** np.linspace(-300, 300, 20001)
     assert np.max(np.abs(pp.det_log(x) - np.log(x)) / np.maximum(np.abs(np.log(x)), 1)) < 4e-16
