@@ -1,0 +1,14 @@
+"""Manual helper (not a test): per-kernel timings of the bench workload, tolerant of
+ablation builds whose results are garbage."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from rescan_line_sted_amd import _lib
+obj, psf, brightness = bench.workload()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+plan = _lib.DeconvPlan(psf, B, 512, 512, dtype=sys.argv[2] if len(sys.argv) > 2 else 'f32')
+plan.set_object(np.broadcast_to(obj, (B, 512, 512)), brightness)
+plan.simulate(seed=1)
+print(json.dumps({k: round(v, 4) for k, v in plan.time_kernels(10).items()}))

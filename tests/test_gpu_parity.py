@@ -153,6 +153,26 @@ def test_batch_of_frames_equals_frames_run_alone(lib, golden, astronaut512):
         assert np.array_equal(one.estimate()[0], est[f])      # bitwise: no cross-frame coupling
 
 
+def test_many_frames_persistent_column_kernel_orders(lib, golden):
+    """B = 16 (work items a multiple of 8: XCD-contiguous order) and B = 5 (fallback
+    order) through the persistent column kernel equal frames computed one by one."""
+    psf = list(golden('g8_fig2_psfs')['1p5x_lr/point_sted_psf'])
+    rng = np.random.default_rng(21)
+    one = lib.DeconvPlan(psf, 1, 128, 128, dtype='f32')
+    for B in (16, 5):
+        objs = rng.random((B, 128, 128)) * 100
+        plan = lib.DeconvPlan(psf, B, 128, 128, dtype='f32')
+        plan.set_object(objs, 1e9)
+        plan.simulate(seed=B)
+        plan.iterate(3)
+        est, noisy = plan.estimate(), plan.measurement()
+        for f in (0, B // 2, B - 1):
+            one.set_object(objs[f:f + 1], 1e9)
+            one.set_measurement(noisy[f:f + 1])
+            one.iterate(3)
+            assert np.array_equal(one.estimate()[0], est[f])
+
+
 # ------------------------------------- BASELINE configs 3 and 5: large images
 def test_2048_line_rescan_batch_vs_oracle(lib, golden):
     """Config 3 shape: synthetic 2048x2048 random object, line-rescan (4 views), a
