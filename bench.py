@@ -174,9 +174,21 @@ def main():
     else:
         pass_bytes, pass_ms = pass2, kt['colconv_Ht'] + kt['rowpass_UPDATE']
     achieved = pass_bytes / (pass_ms * 1e-3) / 1e9
+    # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE /
+    # WRITE_SIZE, separate rocprofv3 passes, gfx950 correction applied): measured offline
+    # with the command recorded in the file, valid for this exact launch shape only.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
+        if (pmc.get('batch') == B and pmc.get('dtype') == args.dtype and pmc.get('n_psf') == V
+                and pmc.get('shape') == [NY, NX] and dom in pmc):
+            traffic = pmc[dom]['hbm_bytes_per_launch']
+    except (OSError, ValueError):
+        pass
     roofline = {
         'bound': 'hbm', 'kernel': dom, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
-        'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+        'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+        'algorithmic_bytes_per_launch_pair': pass_bytes,
         'kernel_avg_ms': kt,
         'kernel_moved_GBps': {k: launches[k][1] * B / (kt[k] * 1e-3) / 1e9 for k in launches},
         'rl_iteration': {'ms': iter_ms, 'algorithmic_GBps': alg_iter / (iter_ms * 1e-3) / 1e9,
