@@ -47,7 +47,8 @@ struct ColParams {
     const cx<T>* tw;        // [Ly] exp(-2 pi i m / Ly)
     int ny, kx, pitch;
     int V;                  // views per frame; blockIdx.y = frame*V + view
-    int in_sb, in_sv;       // input image index = frame*in_sb + view*in_sv
+    int in_sb, in_sv;       // COL_PER_IMAGE: input image index = frame*in_sb + view*in_sv
+    int mode;               // ColMode (wave-private column kernel only; others: per image)
 };
 
 template <class Cfg, int C, typename T, class Sync>
@@ -117,25 +118,39 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
 //      registers, no workgroup barrier; result back to its LDS column
 //   3. the whole workgroup stores rows < ny, coalesced as in 1.
 // psf_hat is read transposed here: psf_hat_t[view][kx][Ly] (contiguous along ky).
-template <class Cfg, int C, typename T, class Sync>
+//
+// p.mode selects how views are walked (blockIdx.y = `by`):
+//   COL_PER_IMAGE  by = frame*V + view: one input image, one output image (H_t per view, V == 1)
+//   COL_H_MULTI    by = frame: ONE forward transform of the frame's spectrum feeds V
+//                  multiply + inverse transforms -> output images frame*V + view   (H, ref:573-576)
+//   COL_HT_SUM     by = frame: the V products FFT_y(in[frame*V+view]) * psf_hat[view] are summed
+//                  in the Fourier domain and inverse transformed once -> output image frame
+//                  (H_t, ref:584-588, with the per-view clamp replaced by one clamp of the sum:
+//                  identical in exact arithmetic, see DESIGN.md "fused views")
+enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2 };
+
+// MODE is a compile-time parameter: each mode is its own kernel, so the single-view path
+// does not inherit the register footprint of the multi-view loops.
+template <class Cfg, int C, int MODE, typename T, class Sync>
 RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
     constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     constexpr int NT = 64 * C;
-    const int w = tid / 64, lane = tid % 64;
-    const int col0 = bx * C;
-    const int frame = by / p.V, view = by % p.V;
-    const size_t img = (size_t)p.ny * p.pitch;
-    const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
-    cx<T>* __restrict__ out = p.out + (size_t)by * img;
-
-    // 1. cooperative tile load (c fastest across lanes), zero fill rows >= ny.
-    //    All global loads are issued before the first LDS write (one latency, not NLD).
     static_assert((L * C) % NT == 0, "tile must divide evenly over the workgroup");
     constexpr int NLD = (L * C) / NT;
-    {
-        cx<T> x[NLD];
+    using FL = PassInfo<Cfg, false, NP - 1>;
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
+    const int w = tid / 64, lane = tid % 64;
+    const int col0 = bx * C, col = col0 + w;
+    const bool colok = col < p.kx;
+    const size_t img = (size_t)p.ny * p.pitch;
+    LdsView<T, 1> view_lds{lds + w * LP};
+
+    // tile element e = tid + it*NT  <->  (row = e / C, column c = e % C)
+    auto load_tile = [&](const cx<T>* __restrict__ in) {
+        cx<T> x[NLD];   // all global loads are issued before the first LDS write
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
@@ -148,18 +163,18 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
             const int e = tid + it * NT;
             lds[(e % C) * LP + lds_pad(e / C)] = x[it];
         }
-    }
-    sync.wg();
-
-    // 2. wave-private transform of column col0 + w
-    const int col = col0 + w;
-    if (col < p.kx) {
-        LdsView<T, 1> view_lds{lds + w * LP};
+    };
+    auto store_tile = [&](cx<T>* __restrict__ out) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const int row = e / C, c = e % C;
+            if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+        }
+    };
+    // v, tl *= psf_hat[view] column (register layout of the last forward pass)
+    auto multiply = [&](cx<T>* v, cx<T>& tl, int view) {
         const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
-        cx<T> v[VMAX];
-        cx<T> tl = mk<T>((T)0, (T)0);
-        run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
-        using FL = PassInfo<Cfg, false, NP - 1>;
 #pragma unroll
         for (int nb = 0; nb < FL::NBM; ++nb) {
             const int j = lane + nb * 64;
@@ -170,9 +185,10 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         }
         if constexpr (FL::TAIL)   // the tail value is output bitrev3(p) of butterfly 64 + jj
             tl = cmul(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
-        run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
-        using IL = PassInfo<Cfg, true, NP - 1>;
-        static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
+    };
+    // inverse transform of (v, tl), result in natural order into this wave's LDS column
+    auto inverse_to_lds = [&](cx<T>* v, cx<T>& tl, const cx<T>* tw) {
+        run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw, sync);
         sync.wave();   // last pass' LDS reads are done before the column is overwritten
 #pragma unroll
         for (int nb = 0; nb < IL::NB; ++nb) {
@@ -182,15 +198,75 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
                 for (int r = 0; r < IL::R; ++r) view_lds.at(j + r * IL::NBF) = v[nb * IL::R + r];
             }
         }
-    }
-    sync.wg();
+    };
 
-    // 3. cooperative store of rows < ny
+    if constexpr (MODE == COL_PER_IMAGE) {
+        const int frame = by / p.V, view = by % p.V;
+        load_tile(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img);
+        sync.wg();
+        if (colok) {
+            cx<T> v[VMAX];
+            cx<T> tl = mk<T>((T)0, (T)0);
+            run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+            multiply(v, tl, view);
+            inverse_to_lds(v, tl, p.tw);
+        }
+        sync.wg();
+        store_tile(p.out + (size_t)by * img);
+    } else if constexpr (MODE == COL_H_MULTI) {
+        load_tile(p.in + (size_t)by * img);
+        sync.wg();
+        cx<T> f[VMAX];
+        cx<T> ftl = mk<T>((T)0, (T)0);
+        if (colok) run_passes<Cfg, false, 0, false>(f, ftl, lane, view_lds, p.tw, sync);
+        for (int view = 0; view < p.V; ++view) {
+            // keep the compiler from hoisting the (view-invariant) twiddle loads out of
+            // this loop: ~60 registers that would cost a workgroup of occupancy
+            const cx<T>* tw = p.tw;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+s"(tw));
+#endif
+            if (colok) {
+                cx<T> v[VMAX];
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-        const int e = tid + it * NT;
-        const int row = e / C, c = e % C;
-        if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+                for (int i = 0; i < VMAX; ++i) v[i] = f[i];
+                cx<T> tl = ftl;
+                multiply(v, tl, view);
+                inverse_to_lds(v, tl, tw);
+            }
+            sync.wg();
+            store_tile(p.out + ((size_t)by * p.V + view) * img);
+            if (view + 1 < p.V) sync.wg();   // the tile is read out before the next inverse scatters into it
+        }
+    } else {   // COL_HT_SUM
+        cx<T> acc[VMAX];
+        cx<T> atl = mk<T>((T)0, (T)0);
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i) acc[i] = mk<T>((T)0, (T)0);
+        for (int view = 0; view < p.V; ++view) {
+            if (view > 0) sync.wg();         // every wave is done with the previous tile
+            load_tile(p.in + ((size_t)by * p.V + view) * img);
+            sync.wg();
+            const cx<T>* tw = p.tw;   // not hoisted out of the view loop (see COL_H_MULTI)
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+s"(tw));
+#endif
+            if (colok) {
+                cx<T> v[VMAX];
+                cx<T> tl = mk<T>((T)0, (T)0);
+                run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw, sync);
+                multiply(v, tl, view);
+#pragma unroll
+                for (int i = 0; i < FL::NBM * FL::R; ++i) acc[i] = acc[i] + v[i];
+                atl = atl + tl;
+            }
+        }
+        if (colok) {
+            sync.wave();
+            inverse_to_lds(acc, atl, p.tw);
+        }
+        sync.wg();
+        store_tile(p.out + (size_t)by * img);
     }
 }
 

@@ -11,6 +11,9 @@
 #ifndef RL_ROW_MIN_WAVES
 #define RL_ROW_MIN_WAVES 5
 #endif
+#ifndef RL_COL_MIN_WAVES
+#define RL_COL_MIN_WAVES 1
+#endif
 #ifndef RL_CFG_L
 #error "compile with -DRL_CFG_L=<length>"
 #endif
@@ -42,8 +45,9 @@ struct DevSync {
 // NOTE: the transform length is a template parameter of the kernels so that the
 // kernels of different lengths (built in separate translation units) have
 // distinct symbol names.
-template <int L, int C, typename T>
-__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C) k_colconv(const ColParams<T> p) {
+template <int L, int C, int MODE, typename T>
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_COL_MIN_WAVES : 1)
+    k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
@@ -61,7 +65,7 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C) k_colconv(const ColParam
         by = w / gx;
     }
     if constexpr (WavePrivate<KCfg>::value)
-        colconv_wave_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
+        colconv_wave_body<KCfg, C, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
         colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
@@ -82,7 +86,14 @@ static constexpr size_t lds_bytes() {
 template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
-    k_colconv<RL_CFG_L, C, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    if (WavePrivate<Cfg>::value && p.mode == COL_H_MULTI)
+        k_colconv<RL_CFG_L, C, COL_H_MULTI, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    else if (WavePrivate<Cfg>::value && p.mode == COL_HT_SUM)
+        k_colconv<RL_CFG_L, C, COL_HT_SUM, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    else if (p.mode == COL_PER_IMAGE)
+        k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -141,8 +152,8 @@ static hipError_t prepare_rows() {
 
 static hipError_t prepare() {
     hipError_t e;
-    if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, float>, lds_bytes<kC32, float>())) != hipSuccess) return e;
-    if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, double>, lds_bytes<kC64, double>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float>, lds_bytes<kC32, float>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double>, lds_bytes<kC64, double>())) != hipSuccess) return e;
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
     return hipSuccess;

@@ -75,6 +75,9 @@ struct rl_deconv {
     void* scratch = nullptr;   // [B*V][ny][nx] staging for rl_forward / rl_adjoint
     size_t bytes = 0;
     bool have_obj = false, have_meas = false;
+    // H_t views summed before the inverse transforms (one clamp of the sum instead of one per
+    // view, ref:587): default for f32 plans, off for f64 (faithful); RLSTED_FUSE_VIEWS=0/1 overrides
+    bool fuse_views = false;
     bool est_ready = false;    // est holds a valid estimate
     bool spec_valid = false;   // spec_a holds rowFFT(est)
     long iterations = 0;
@@ -85,28 +88,29 @@ struct rl_deconv {
     size_t n_img() const { return (size_t)ny * nx; }
     size_t n_spec() const { return (size_t)ny * pitch; }
 
+    enum ColKind { COL_H, COL_HT_VIEW, COL_HT_FUSED };
+    bool wave_private_y() const { return ty->psf_transposed != 0; }   // multi-view modes exist there only
     template <typename T>
-    ColParams<T> colp(const void* in, void* out, bool h_mode) const {
+    int col_t(const void* in, void* out, int frames, ColKind kind) {
         ColParams<T> p;
         p.in = (const cx<T>*)in;
         p.out = (cx<T>*)out;
         p.psf_hat = (const cx<T>*)psf_hat;
         p.tw = (const cx<T>*)twy;
         p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V;
-        p.in_sb = h_mode ? 1 : V;
-        p.in_sv = h_mode ? 0 : 1;
-        return p;
-    }
-    int col(const void* in, void* out, int frames, bool h_mode) {
-        const int C = ty->C[dtype];
-        const unsigned gx = (unsigned)((kx + C - 1) / C), gy = (unsigned)(frames * V);
-        if (dtype == RL_F32) {
-            auto p = colp<float>(in, out, h_mode);
-            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
-        } else {
-            auto p = colp<double>(in, out, h_mode);
-            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
+        unsigned gy = (unsigned)(frames * V);
+        p.mode = COL_PER_IMAGE;
+        p.in_sb = kind == COL_H ? 1 : V;
+        p.in_sv = kind == COL_H ? 0 : 1;
+        if (V > 1 && wave_private_y() && kind != COL_HT_VIEW) {
+            p.mode = kind == COL_H ? COL_H_MULTI : COL_HT_SUM;
+            gy = (unsigned)frames;
+        } else if (kind == COL_HT_FUSED && V > 1) {
+            return fail(RL_ERR_STATE, "internal: fused H_t needs a wave-private column transform");
         }
+        const int C = ty->C[dtype];
+        const unsigned gx = (unsigned)((kx + C - 1) / C);
+        HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess)
@@ -115,9 +119,13 @@ struct rl_deconv {
         }
         return RL_OK;
     }
+    int col(const void* in, void* out, int frames, ColKind kind) {
+        return dtype == RL_F32 ? col_t<float>(in, out, frames, kind) : col_t<double>(in, out, frames, kind);
+    }
+    int col(const void* in, void* out, int frames, bool h_mode) { return col(in, out, frames, h_mode ? COL_H : COL_HT_VIEW); }
     template <typename T>
     int row_t(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-              const void* scale) {
+              const void* scale, int views) {
         RowParams<T> p;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -126,7 +134,7 @@ struct rl_deconv {
         p.norm = (const T*)nrm;
         p.scale = (const T*)scale;
         p.tw = (const cx<T>*)twx;
-        p.ny = ny; p.nx = nx; p.pitch = pitch; p.V = V;
+        p.ny = ny; p.nx = nx; p.pitch = pitch; p.V = views;
         const int Q = tx->Q[dtype];
         const unsigned pairs = (unsigned)((ny + 1) / 2);
         HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
@@ -140,9 +148,10 @@ struct rl_deconv {
         return RL_OK;
     }
     int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-            const void* scale = nullptr) {
-        return dtype == RL_F32 ? row_t<float>(mode, gy, spec_in, spec_out, src, dst, nrm, scale)
-                               : row_t<double>(mode, gy, spec_in, spec_out, src, dst, nrm, scale);
+            const void* scale = nullptr, int views = -1) {
+        if (views < 0) views = V;
+        return dtype == RL_F32 ? row_t<float>(mode, gy, spec_in, spec_out, src, dst, nrm, scale, views)
+                               : row_t<double>(mode, gy, spec_in, spec_out, src, dst, nrm, scale, views);
     }
 
     // host double [n] -> device dtype
@@ -202,8 +211,14 @@ struct rl_deconv {
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
         RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
-        RL_TRY(col(sb, sb, nf, false));                                                                  // H_t, column part
-        RL_TRY(row(ROW_UPDATE, (unsigned)nf, sb, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));   // est *= H_t / norm
+        if (fuse_views && V > 1 && wave_private_y()) {
+            // views summed in the Fourier domain: one inverse column + one inverse row transform per frame
+            RL_TRY(col(sb, sa, nf, COL_HT_FUSED));
+            RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm, nullptr, 1));
+        } else {
+            RL_TRY(col(sb, sb, nf, false));                                                                  // H_t, column part
+            RL_TRY(row(ROW_UPDATE, (unsigned)nf, sb, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));   // est *= H_t / norm
+        }
         return RL_OK;
     }
     int start_estimate() {
@@ -380,6 +395,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     rl_deconv* h = new rl_deconv;
     h->ctx = ctx;
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
+    h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     int r = deconv_build(h, psfs);
     if (r != RL_OK) {
         std::string keep = rl::last_error();
@@ -578,8 +594,15 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
             switch (which) {
                 case 0: RL_TRY(h->col(h->spec_a, h->spec_b, h->B, true)); break;
                 case 1: RL_TRY(h->row(ROW_RATIO, (unsigned)(h->B * h->V), h->spec_b, h->spec_b, h->meas, nullptr, nullptr)); break;
-                case 2: RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false)); break;
-                case 3: RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_b, h->spec_a, nullptr, h->est, h->norm)); break;
+                case 2:   // as iterate_chunk(): fused (Fourier-domain view sum) or per view
+                    if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->spec_b, h->spec_a, h->B, rl_deconv::COL_HT_FUSED));
+                    else RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false));
+                    break;
+                case 3:
+                    if (h->fuse_views && h->V > 1 && h->wave_private_y())
+                        RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_a, h->spec_a, nullptr, h->est, h->norm, nullptr, 1));
+                    else RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_b, h->spec_a, nullptr, h->est, h->norm));
+                    break;
                 case 4: RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->obj, nullptr, nullptr)); break;
                 case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 1, RL_RNG_PHILOX, h->scratch, s)); break;
             }

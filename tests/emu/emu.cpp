@@ -76,7 +76,7 @@ static std::vector<cx<T>> twiddles() {   // the per-pass table the device plan u
 
 template <int L, typename T>
 static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitch, int V, int frames,
-                 int in_sb, int in_sv) {
+                 int in_sb, int in_sv, int mode) {
     using CF = CfgFor<L>;
     using Cfg = typename CF::Cfg;
     constexpr int C = sizeof(T) == 4 ? CF::C32 : CF::C64;
@@ -87,10 +87,17 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     p.psf_hat = reinterpret_cast<const cx<T>*>(psf_hat);
     p.tw = tw.data();
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
-    run_grid((kx + C - 1) / C, frames * V, Cfg::T * C, (size_t)C * LdsLen<L>::value * sizeof(cx<T>),
+    p.mode = mode;
+    const int gy = (mode == COL_PER_IMAGE) ? frames * V : frames;   // as rlsted.cpp col_t()
+    if (mode != COL_PER_IMAGE && !WavePrivate<Cfg>::value) return -3;
+    run_grid((kx + C - 1) / C, gy, Cfg::T * C, (size_t)C * LdsLen<L>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  if constexpr (WavePrivate<Cfg>::value)
-                     colconv_wave_body<Cfg, C, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                     switch (mode) {   // same dispatch as launch_col_t in fft_kernels.hip
+                         case COL_H_MULTI: colconv_wave_body<Cfg, C, COL_H_MULTI, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s); break;
+                         case COL_HT_SUM: colconv_wave_body<Cfg, C, COL_HT_SUM, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s); break;
+                         default: colconv_wave_body<Cfg, C, COL_PER_IMAGE, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                     }
                  else
                      colconv_body<Cfg, C, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
              });
@@ -152,12 +159,12 @@ int emu_geometry(int L, int* T, int* C, int* Q) {
 }
 
 int emu_col_f64(int L, const double* in, double* out, const double* psf_hat, int ny, int kx, int pitch, int V,
-                int frames, int in_sb, int in_sv) {
-    DISPATCH_L(L, (col_t<LL, double>(in, out, psf_hat, ny, kx, pitch, V, frames, in_sb, in_sv)))
+                int frames, int in_sb, int in_sv, int mode) {
+    DISPATCH_L(L, (col_t<LL, double>(in, out, psf_hat, ny, kx, pitch, V, frames, in_sb, in_sv, mode)))
 }
 int emu_col_f32(int L, const float* in, float* out, const float* psf_hat, int ny, int kx, int pitch, int V,
-                int frames, int in_sb, int in_sv) {
-    DISPATCH_L(L, (col_t<LL, float>(in, out, psf_hat, ny, kx, pitch, V, frames, in_sb, in_sv)))
+                int frames, int in_sb, int in_sv, int mode) {
+    DISPATCH_L(L, (col_t<LL, float>(in, out, psf_hat, ny, kx, pitch, V, frames, in_sb, in_sv, mode)))
 }
 int emu_row_f64(int L, int mode, const double* spec_in, double* spec_out, const double* src, double* dst,
                 const double* norm, const double* scale, int ny, int nx, int pitch, int V, int gy) {

@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import bench
 from rescan_line_sted_amd import _lib
 obj, psf, brightness = bench.workload()
+if len(sys.argv) > 3:      # e.g. 2p0x_lr/line_sted_psfs
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
+    psf = [p[None] for p in g[sys.argv[3]][:, 0]]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 plan = _lib.DeconvPlan(psf, B, 512, 512, dtype=sys.argv[2] if len(sys.argv) > 2 else 'f32')
 plan.set_object(np.broadcast_to(obj, (B, 512, 512)), brightness)

@@ -80,11 +80,21 @@ class EmuPlan:
                self.ny, self.nx, self.pitch, self.V, gy)
         assert rc == 0
 
-    def col(self, spec_in, spec_out, frames, h_mode):
+    def col(self, spec_in, spec_out, frames, kind):
+        """kind: 'H' (frame spectrum -> V images), 'HT' (per view), 'HT_SUM' (views summed in
+        the Fourier domain -> one image per frame).  Same mode selection as rlsted.cpp col_t()."""
+        if kind is True:
+            kind = 'H'
+        elif kind is False:
+            kind = 'HT'
         f = getattr(self.lib, 'emu_col_' + self.sfx)
+        mode = 0
+        if self.V > 1 and self.transposed and kind != 'HT':
+            mode = 1 if kind == 'H' else 2
+        assert not (kind == 'HT_SUM' and mode == 0 and self.V > 1)
         rc = f(self.Ly, _p(spec_in), _p(spec_out), _p(self.psf_hat), self.ny,
                self.kx, self.pitch, self.V, frames,
-               1 if h_mode else self.V, 0 if h_mode else 1)
+               1 if kind == 'H' else self.V, 0 if kind == 'H' else 1, mode)
         assert rc == 0
 
     def spec(self, n):
@@ -110,7 +120,7 @@ class EmuPlan:
         self.row(ROW_ADJ, 1, spec_in=sb, dst=norm)
         return norm
 
-    def rl(self, meas, K):
+    def rl(self, meas, K, fuse=False):
         B = meas.shape[0]
         meas = np.ascontiguousarray(meas.reshape(B * self.V, self.ny, self.nx), dtype=self.rt)
         norm = self.normalization()
@@ -120,8 +130,14 @@ class EmuPlan:
         for _ in range(K):
             self.col(sa, sb, B, True)
             self.row(ROW_RATIO, B * self.V, spec_in=sb, spec_out=sb, src=meas)
-            self.col(sb, sb, B, False)
-            self.row(ROW_UPDATE, B, spec_in=sb, spec_out=sa, dst=est, norm=norm)
+            if fuse and self.V > 1:
+                self.col(sb, sa, B, 'HT_SUM')
+                keepV, self.V = self.V, 1          # the UPDATE row pass sees one (summed) view
+                self.row(ROW_UPDATE, B, spec_in=sa, spec_out=sa, dst=est, norm=norm)
+                self.V = keepV
+            else:
+                self.col(sb, sb, B, False)
+                self.row(ROW_UPDATE, B, spec_in=sb, spec_out=sa, dst=est, norm=norm)
         return est, norm
 
 
@@ -199,6 +215,31 @@ def test_richardson_lucy_matches_oracle(emu, dtype, tol):
     meas = np.array(d.noisy_measurement)[None, :, 0]       # (B=1, V, ny, nx)
     est, _ = pl.rl(meas, 4)
     assert max_rel(est[0], d.estimate[0]) < tol
+
+
+def test_multi_view_column_modes_on_wave_private_length(emu):
+    """Ly = 192 (wave private): H with one shared forward transform, H_t summed in the
+    Fourier domain, and the fused RL iteration, against the oracle."""
+    rng = np.random.default_rng(6)
+    ny, nx = 150, 40
+    psfs = [rng.random((1, 9, 5)), rng.random((1, 7, 7)), rng.random((1, 11, 3))]
+    pl = EmuPlan(emu, psfs, ny, nx, 192, 64)
+    assert pl.transposed == 1
+    x = rng.random((2, ny, nx))
+    got, _ = pl.H(x)                                        # COL_H_MULTI
+    d = orc.Deconvolver(psfs)
+    ref = d.H(x)
+    for v in range(3):
+        assert max_rel(got[:, v], ref[v]) < 1e-13
+    obj = rng.random((1, ny, nx)) * 30
+    d.create_data_from_object(obj, random_seed=0)
+    for _ in range(3):
+        d.iterate()
+    meas = np.array(d.noisy_measurement)[None, :, 0]
+    est_f, _ = pl.rl(meas, 3, fuse=True)                    # COL_HT_SUM + single-view UPDATE
+    est_u, _ = pl.rl(meas, 3, fuse=False)
+    assert max_rel(est_u[0], d.estimate[0]) < 1e-11
+    assert max_rel(est_f[0], d.estimate[0]) < 1e-11         # no negative lobes here: clamp of sum == sum of clamps
 
 
 def test_golden_rl_through_emulated_kernels(emu, golden):
