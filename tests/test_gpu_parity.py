@@ -112,6 +112,38 @@ def test_drop_in_deconvolver_reproduces_reference_run(st, golden, tmp_path):
     assert d.estimate.shape == (1, 128, 128) and d.estimate.dtype == np.float64
 
 
+def test_record_and_load_round_trip(st, golden, tmp_path):
+    """record_data / record_iteration (ref:533-565) write ImageJ TIFs through the np_tif
+    mirror; load_data_from_tif (ref:514-518) feeds a saved measurement back in."""
+    from rescan_line_sted_amd import np_tif
+    g, psfs, objs = golden('g5_rl'), golden('g8_fig2_psfs'), golden('objects')
+    prefix = str(tmp_path / 'out') + '/rings_'
+    d = st.Deconvolver(list(psfs['1p5x_lr/point_sted_psf']), prefix, verbose=False)
+    d.create_data_from_object(objs['rings'].astype(np.float64), total_brightness=5e10, random_seed=0)
+    d.record_data()
+    for name, shape in (('psfs', (1, 107, 107)), ('object', (1, 128, 128)),
+                        ('noiseless_measurement', (1, 128, 128)), ('noisy_measurement', (1, 128, 128))):
+        a = np_tif.tif_to_array(prefix + name + '.tif')
+        assert a.shape == shape and a.dtype == np.float32
+    assert np.array_equal(np_tif.tif_to_array(prefix + 'object.tif'), d.true_object.astype(np.float32))
+    for i, save in st.logarithmic_progress(range(3), verbose=False):
+        d.iterate()
+        if save:
+            d.record_iteration()
+    hist = np_tif.tif_to_array(prefix + 'estimate_history.tif')
+    assert hist.shape == (2, 128, 128) and d.saved_iterations == [2, 3]
+    assert np.array_equal(hist[-1], d.estimate[0].astype(np.float32))
+    ft = np_tif.tif_to_array(prefix + 'estimate_FT_error_history.tif')
+    want = np.log(1 + np.abs(np.fft.fftshift(np.fft.fftn(d.estimate - d.true_object, axes=(1, 2)), axes=(1, 2))))
+    assert max_rel(ft[-1], want[0]) < 1e-6
+    # a second deconvolver that only sees the saved measurement
+    e = st.Deconvolver(list(psfs['1p5x_lr/point_sted_psf']), prefix, verbose=False)
+    e.load_data_from_tif(prefix + 'noisy_measurement.tif')
+    for _ in range(3):
+        e.iterate()
+    assert max_rel(e.estimate, d.estimate) < 1e-6            # the TIF stores float32
+
+
 # ----------------------------------------- BASELINE size: 512 x 512, K = 20
 @pytest.fixture(scope='module')
 def astronaut512(golden):
