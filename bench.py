@@ -80,11 +80,17 @@ def main():
     ap.add_argument('--kernel-reps', type=int, default=20)
     args = ap.parse_args()
 
+    # Exactly ONE line goes to stdout.  Libraries loaded below (RCCL prints a version banner
+    # there) get stderr instead: the process-level stdout is parked and restored for the JSON.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -213,10 +219,12 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(obj, psf, brightness)
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
