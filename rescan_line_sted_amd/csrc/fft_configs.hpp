@@ -37,7 +37,7 @@ struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
 template <>
 struct CfgFor<1152> { // 1024 + 53
     using Cfg = FftCfg<1152, 144, 8, 9, 16>;
-    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
+    static constexpr int C32 = 4, C64 = 4, Q32 = 4, Q64 = 4;   // T*C <= 1024 threads
 };
 template <>
 struct CfgFor<2304> { // 2048 + 53
@@ -50,5 +50,15 @@ struct CfgFor<4608> { // 4096 + 53: one transform per workgroup (functional supp
     using Cfg = FftCfg<4608, 576, 8, 8, 8, 9>;
     static constexpr int C32 = 1, C64 = 1, Q32 = 1, Q64 = 1;
 };
+
+// geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads
+template <int L>
+constexpr bool cfg_fits() {
+    using CF = CfgFor<L>;
+    return CF::Cfg::T * CF::C32 <= 1024 && CF::Cfg::T * CF::C64 <= 1024 && CF::Cfg::T * CF::Q32 <= 1024 && CF::Cfg::T * CF::Q64 <= 1024;
+}
+static_assert(cfg_fits<64>() && cfg_fits<192>() && cfg_fits<256>() && cfg_fits<576>() && cfg_fits<1152>() &&
+                  cfg_fits<2304>() && cfg_fits<4608>(),
+              "workgroup size above 1024 threads");
 
 }  // namespace rl

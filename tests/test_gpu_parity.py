@@ -303,6 +303,45 @@ def test_device_poisson_bit_exact_vs_oracle_twin(lib, golden):
             assert np.array_equal(got, want), (dtype, tb)
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_random_shapes_vs_oracle(lib, seed):
+    """Random image / PSF shapes (odd sizes, even PSFs, 1-10 views, every transform length
+    up to 1152) through H, H_t and two RL iterations, f64 against the oracle at 1e-11 and
+    f32 at the BASELINE tolerance."""
+    rng = np.random.default_rng(1000 + seed)
+    target = [64, 192, 256, 576, 1152, 192, 256, 576, 64, 192, 576, 256][seed]
+    lo = {64: 2, 192: 70, 256: 200, 576: 260, 1152: 600}[target]
+    py, px = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    hy, hx = max((py - 1) // 2, py - 1 - (py - 1) // 2), max((px - 1) // 2, px - 1 - (px - 1) // 2)
+    ny = int(rng.integers(max(lo - hy, 1), target - hy + 1))
+    nx = int(rng.integers(max(lo - hx, 1), target - hx + 1))
+    if target == 1152:
+        nx = int(rng.integers(2, 60))                     # keep the oracle cheap: only Ly is large
+    V = int(rng.integers(1, 11)) if ny * nx < 40000 else int(rng.integers(1, 4))
+    B = int(rng.integers(1, 4))
+    psfs = [rng.random((1, py, px)) + 0.01 for _ in range(V)]
+    x = rng.random((B, ny, nx)) * 20
+    d = orc.Deconvolver(psfs)
+    Hx = d.H(x)
+    y = [rng.random((B, ny, nx)) for _ in range(V)]
+    Ht = d.H_t(y)
+    d.create_data_from_object(x, random_seed=seed)
+    d.iterate()
+    d.iterate()
+    for dtype, tol in (('f64', 1e-11), ('f32', F32_TOL)):
+        plan = lib.DeconvPlan(psfs, B, ny, nx, dtype=dtype)
+        info = plan.info()
+        assert info['ly'] == lib.lib.rl_fft_length_for(ny + hy) and info['lx'] == lib.lib.rl_fft_length_for(nx + hx)
+        got = plan.forward(x)
+        for v in range(V):
+            assert max_rel(got[:, v], Hx[v]) < tol, (dtype, 'H', v, ny, nx, py, px, V)
+        assert max_rel(plan.adjoint(np.stack(y, axis=1)), Ht) < 5 * tol, (dtype, 'Ht', ny, nx, py, px, V)
+        plan.set_measurement(np.stack(d.noisy_measurement, axis=1))
+        plan.iterate(2)
+        assert max_rel(plan.estimate(), d.estimate) < 10 * tol, (dtype, 'RL', ny, nx, py, px, V)
+        del plan
+
+
 def test_edge_cases(lib):
     rng = np.random.default_rng(0)
     # PSF larger than the image, 1-pixel image, single row / column
