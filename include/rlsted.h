@@ -141,6 +141,12 @@ int rl_psf_report(rl_ctx* ctx, int psf_type, double excitation_brightness, doubl
                   double steps_per_excitation_psf_width, double pulses_per_position,
                   double* arrays_out, double* report_out);
 
+/* rotate of line_sted_figure_2.py:264-272 for one [ny][nx] plane (general angles; the
+ * caller keeps the script's exact 0 and 90 degree special cases): cubic B-spline
+ * rotation about the centre as scipy.ndimage.rotate(order=3, reshape=False), then
+ * clipped to [0, 1.1 * max(in)].  Host in / out, float64.                       */
+int rl_rotate_psf(rl_ctx* ctx, const double* in, double* out, int ny, int nx, double degrees);
+
 /* Per-kernel device time: launches each kernel of the RL iteration `reps`
  * times back to back between two hipEvents on the plan's stream and returns
  * the average milliseconds per launch in avg_ms[6] = { column pass (H),

@@ -48,6 +48,7 @@ PROTOTYPES = {
     'rl_gauss_fit': (_i, [_dp, _i, _dp, _c.POINTER(_i)]),
     'rl_gaussian_filter': (_i, [_vp, _dp, _dp, _i, _i, _i, _dp, _c.c_double]),
     'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
+    'rl_rotate_psf': (_i, [_vp, _dp, _dp, _i, _i, _c.c_double]),
     'rl_psf_report': (_i, [_vp, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _dp, _dp]),
 }
 

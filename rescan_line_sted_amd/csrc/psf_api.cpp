@@ -75,6 +75,22 @@ int rl_gaussian_filter(rl_ctx* ctx, const double* in, double* out, int nz, int n
     return RL_OK;
 }
 
+// rotate of line_sted_figure_2.py:264-272 for one (ny, nx) plane: cubic-spline rotation
+// about the centre (scipy.ndimage.rotate, reshape=False), clipped to [0, 1.1*max(in)].
+int rl_rotate_psf(rl_ctx* ctx, const double* in, double* out, int ny, int nx, double degrees) {
+    if (!ctx || !in || !out) return fail(RL_ERR_INVALID, "NULL argument");
+    if (ny < 1 || nx < 1) return fail(RL_ERR_INVALID, "non-positive shape");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ny * nx;
+    double* work = nullptr;
+    RL_TRY(ctx->psf_workspace(3 * n + 8, &work));
+    HIP_TRY(hipMemcpyAsync(work, in, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(psf_spline_rotate(work, work + n, work + 2 * n, work + 3 * n, ny, nx, degrees, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, work + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RL_OK;
+}
+
 // generate_psfs (:168-363) for shape (1, ny, nx).
 //   psf_type      0 = point, 1 = line
 //   rescan_ratio  line only: > 0 forces the integer ratio, <= 0 derives it from the

@@ -164,6 +164,66 @@ __global__ void k_rescan_bin(const double* __restrict__ cumu, int ny, int nx, in
     rescan[e] = acc;
 }
 
+// ---- cubic B-spline rotation of a PSF, line_sted_figure_2.py:264-272 ------------------
+// scipy.ndimage.rotate(order=3, reshape=False, mode='constant'): recursive prefilter
+// with mirror boundaries along both axes, then the spline evaluated at the rotated
+// coordinates (source coordinates outside [0, n-1] give 0), clipped to [0, 1.1 max].
+// One thread filters one line (n <= a few hundred): the recursion is serial by nature.
+__global__ void k_spline_prefilter(double* __restrict__ a, int ny, int nx, int axis) {
+    const int line = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = axis == 0 ? ny : nx, lines = axis == 0 ? nx : ny;
+    if (line >= lines || n < 2) return;
+    double* c = a + (axis == 0 ? line : (size_t)line * nx);
+    const int st = axis == 0 ? nx : 1;
+    const double z = -0.26794919243112270647255365849413;          // sqrt(3) - 2
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    for (int i = 0; i < n; ++i) c[(size_t)i * st] *= gain;
+    const double zn1 = pow(z, (double)(n - 1));
+    double c0 = c[0] + zn1 * c[(size_t)(n - 1) * st], zi = z;
+    for (int i = 1; i < n - 1; ++i) {
+        c0 += zi * (c[(size_t)i * st] + zn1 * c[(size_t)(n - 1 - i) * st]);
+        zi *= z;
+    }
+    c[0] = c0 / (1.0 - zn1 * zn1);
+    for (int i = 1; i < n; ++i) c[(size_t)i * st] += z * c[(size_t)(i - 1) * st];
+    c[(size_t)(n - 1) * st] = (z * c[(size_t)(n - 2) * st] + c[(size_t)(n - 1) * st]) * z / (z * z - 1.0);
+    for (int i = n - 2; i >= 0; --i) c[(size_t)i * st] = z * (c[(size_t)(i + 1) * st] - c[(size_t)i * st]);
+}
+
+__device__ __forceinline__ int mirror_index(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i = (i < 0 ? -i : i) % p;
+    return i >= n ? p - i : i;
+}
+
+__global__ void k_spline_rotate(const double* __restrict__ coef, double* __restrict__ out, int ny, int nx, double c,
+                                double s, const double* __restrict__ vmax) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const int ox = e % nx, oy = e / nx;
+    const double cy = (ny - 1) * 0.5, cx = (nx - 1) * 0.5;
+    double y = c * oy + s * ox + (cy - (c * cy + s * cx));
+    double x = -s * oy + c * ox + (cx - (-s * cy + c * cx));
+    const double tol = 1e-10;
+    double r = 0.0;
+    if (y >= -tol && y <= ny - 1 + tol && x >= -tol && x <= nx - 1 + tol) {
+        y = fmin(fmax(y, 0.0), (double)(ny - 1));
+        x = fmin(fmax(x, 0.0), (double)(nx - 1));
+        const double fy = floor(y), fx = floor(x), ty = y - fy, tx = x - fx;
+        const double wy[4] = {(1 - ty) * (1 - ty) * (1 - ty) / 6, (3 * ty * ty * ty - 6 * ty * ty + 4) / 6,
+                              (-3 * ty * ty * ty + 3 * ty * ty + 3 * ty + 1) / 6, ty * ty * ty / 6};
+        const double wx[4] = {(1 - tx) * (1 - tx) * (1 - tx) / 6, (3 * tx * tx * tx - 6 * tx * tx + 4) / 6,
+                              (-3 * tx * tx * tx + 3 * tx * tx + 3 * tx + 1) / 6, tx * tx * tx / 6};
+        for (int i = 0; i < 4; ++i) {
+            const int yy = mirror_index((int)fy - 1 + i, ny);
+            for (int j = 0; j < 4; ++j) r += wy[i] * wx[j] * coef[(size_t)yy * nx + mirror_index((int)fx - 1 + j, nx)];
+        }
+    }
+    const double hi = 1.1 * vmax[0];                                  // np.clip(rotated, 0, 1.1 * x.max())
+    out[e] = r < 0.0 ? 0.0 : (r > hi ? hi : r);
+}
+
 static inline unsigned nblk(int n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t psf_blur_axis(const double* in, double* out, int nz, int ny, int nx, int axis, const double* w, int radius,
@@ -195,6 +255,20 @@ hipError_t psf_rescan(const double* sted_row, const double* w, int radius, const
     k_descan<<<nblk(ny * nx), 256, 0, s>>>(b0, ry, rx, ny, nx, descan);
     k_rescan_cumu<<<nblk(ny * ratio * nx), 256, 0, s>>>(b0, ry, rx, ny, nx, ratio, cumu);
     k_rescan_bin<<<nblk(ny * nx), 256, 0, s>>>(cumu, ny, nx, ratio, rescan);
+    return hipGetLastError();
+}
+
+// in: [ny][nx] device; work: [ny][nx] device scratch (receives the spline coefficients);
+// vmax: device scalar scratch
+hipError_t psf_spline_rotate(const double* in, double* work, double* out, double* vmax, int ny, int nx,
+                             double degrees, hipStream_t s) {
+    hipError_t e = hipMemcpyAsync(work, in, (size_t)ny * nx * sizeof(double), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    k_reduce<<<1, 1024, 0, s>>>(in, ny * nx, 1, 0, vmax);
+    k_spline_prefilter<<<nblk(nx), 256, 0, s>>>(work, ny, nx, 0);
+    k_spline_prefilter<<<nblk(ny), 256, 0, s>>>(work, ny, nx, 1);
+    const double th = degrees * 0.017453292519943295769236907684886;
+    k_spline_rotate<<<nblk(ny * nx), 256, 0, s>>>(work, out, ny, nx, cos(th), sin(th), vmax);
     return hipGetLastError();
 }
 

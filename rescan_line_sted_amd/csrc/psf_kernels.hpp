@@ -14,4 +14,6 @@ hipError_t psf_stage2(const double* exc, double* dep, const double* maxes, doubl
                       double* dep_frac, double* sted, int n, hipStream_t s);
 hipError_t psf_rescan(const double* sted_row, const double* w, int radius, const double* ry, const double* rx, int ny,
                       int nx, int ratio, double* b0, double* cumu, double* descan, double* rescan, hipStream_t s);
+hipError_t psf_spline_rotate(const double* in, double* work, double* out, double* vmax, int ny, int nx,
+                             double degrees, hipStream_t s);
 }  // namespace rl

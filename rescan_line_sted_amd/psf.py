@@ -340,3 +340,83 @@ def tune_psf(psf_type, scan_type, desired_resolution_improvement,
         print()
     results.update(args)                                                       # ref:475
     return results
+
+
+# ---------------------------------------------------------------------------
+# The figure-2 harness around the module: PSF rotation and the
+# point / line operating-point pair, line_sted_figure_2.py:183-248, 264-272.
+# ---------------------------------------------------------------------------
+def rotate(x, degrees):
+    """line_sted_figure_2.py:264-272: (1, ny, nx) PSF rotated in its plane; exact
+    for 0 and 90 degrees, cubic-spline + clip to [0, 1.1 max] otherwise (device)."""
+    if degrees == 0:
+        return x
+    if degrees == 90:
+        return np.rot90(np.squeeze(x)).reshape(x.shape)
+    x = as_f64(x)
+    out = np.empty_like(x)
+    for z in range(x.shape[0]):
+        check(lib.rl_rotate_psf(_ctx().handle, ptr(x[z]), ptr(out[z]), x.shape[1], x.shape[2], float(degrees)))
+    return out
+
+
+def psf_comparison_pair(point_resolution_improvement, line_resolution_improvement,
+                        point_emissions_per_molecule, line_emissions_per_molecule,
+                        line_scan_type, line_num_orientations,
+                        max_excitation_brightness=0.25, steps_per_improved_psf_width=4,
+                        steps_per_excitation_psf_width=25):
+    """line_sted_figure_2.py:183-248: tune a point-STED and a line-STED operating
+    point of equal dose, sample both PSFs at the display resolution, normalise them to
+    their emission level and fan the line PSF out over its scan orientations."""
+    point = tune_psf('point', 'descanned', float(point_resolution_improvement),
+                     float(point_emissions_per_molecule),
+                     max_excitation_brightness=max_excitation_brightness,
+                     steps_per_improved_psf_width=float(steps_per_improved_psf_width))
+    line = tune_psf('line', line_scan_type, float(line_resolution_improvement),
+                    float(line_emissions_per_molecule),
+                    max_excitation_brightness=max_excitation_brightness,
+                    steps_per_improved_psf_width=float(steps_per_improved_psf_width))
+    fine_point = psf_report('point', point['excitation_brightness'], point['depletion_brightness'],
+                            steps_per_excitation_psf_width, point['pulses_per_position'], verbose=False)
+    fine_line = psf_report('line', line['excitation_brightness'], line['depletion_brightness'],
+                           steps_per_excitation_psf_width, line['pulses_per_position'], verbose=False)
+    point_sted_psf = [point['expected_emission'] *
+                      (fine_point['psfs']['descan_sted'] / fine_point['psfs']['descan_sted'].sum())]
+    assert line['pulses_per_position'] >= line_num_orientations          # script :239
+    which = {'descanned': 'descan_sted', 'rescanned': 'rescan_sted'}[line_scan_type]
+    base = fine_line['psfs'][which] / fine_line['psfs'][which].sum()
+    line_sted_psfs = [1 / line_num_orientations * line['expected_emission'] * rotate(base, angle)
+                      for angle in np.arange(0, 180, 180 / line_num_orientations)]
+    return {'point_sted_psf': point_sted_psf, 'line_sted_psfs': line_sted_psfs,
+            'point': point, 'line': line}
+
+
+# The twelve hand-tuned comparisons of the figure-2 script (line_sted_figure_2.py:77-162):
+# name -> (point R, line R, point emissions, line emissions, line scan type, orientations, max excitation)
+FIGURE_2_OPERATING_POINTS = {
+    '1p0x_ld': (0.99, 0.99, 4, 4, 'descanned', 1, 0.01),
+    '1p0x_lr': (0.99, 1.38282445, 4, 4, 'rescanned', 2, 0.01),
+    '1p5x_ld': (1.5, 2.68125, 4, 2.825, 'descanned', 3, 0.25),
+    '1p5x_lr': (1.5, 2.95425, 4, 2.618, 'rescanned', 3, 0.25),
+    '2p0x_ld': (2, 4.04057, 4, 3.007, 'descanned', 4, 0.25),
+    '2p0x_lr': (2, 4.07614, 4, 3.0227, 'rescanned', 4, 0.25),
+    '2p5x_ld': (2.5, 5.13325, 4, 3.792, 'descanned', 6, 0.25),
+    '2p5x_lr': (2.5, 5.15129, 4, 3.8, 'rescanned', 6, 0.25),
+    '3p0x_ld': (3, 5.94563, 4, 5.034, 'descanned', 8, 0.25),
+    '3p0x_lr': (3, 5.95587, 4, 5.0385, 'rescanned', 8, 0.25),
+    '4p0x_ld': (4, 7.8386627, 4, 7.371, 'descanned', 10, 0.25),
+    '4p0x_lr': (4, 7.840982, 4, 7.37195, 'rescanned', 10, 0.25),
+}
+
+
+def figure_2_psfs(names=None):
+    """The PSF sets of calculate_psfs (line_sted_figure_2.py:66-181) for the named
+    comparisons (default: all twelve): {name + '_point_sted' / '_line_N_angles_sted': [psfs]}."""
+    out, comparisons = {}, {}
+    for name in (names or FIGURE_2_OPERATING_POINTS):
+        pr, lr, pe, le, scan, nori, maxexc = FIGURE_2_OPERATING_POINTS[name]
+        c = psf_comparison_pair(pr, lr, pe, le, scan, nori, max_excitation_brightness=maxexc)
+        comparisons[name] = c
+        out[name + '_point_sted'] = c['point_sted_psf']
+        out[name + '_line_%i_angles_sted' % len(c['line_sted_psfs'])] = c['line_sted_psfs']
+    return out, comparisons

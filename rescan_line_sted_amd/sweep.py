@@ -1,0 +1,65 @@
+"""Parameter sweeps over independent simulations (BASELINE config 4: "all test
+objects x doses x scan modes x seeds"), the workload of the reference's figure-2
+script (line_sted_figure_2.py:29-57: one Deconvolver per PSF set and test image,
+create_data_from_object + N x iterate), batched and -- optionally -- sharded over
+GPUs with `sharding.run_sharded`.
+
+A task is (object name, PSF-set name, seed).  Tasks that share a PSF set, an image
+shape and a seed become the frames of one device plan (the frame index enters the
+Philox counter, so every frame still draws its own noise).
+"""
+import numpy as np
+
+from . import sharding
+from ._lib import DeconvPlan, RNG_PHILOX
+
+
+def make_tasks(objects, psf_sets, seeds):
+    """All (object, psf set, seed) combinations, in a deterministic order."""
+    return [(o, p, int(s)) for p in sorted(psf_sets) for s in seeds for o in sorted(objects)]
+
+
+def task_costs(tasks, objects, psf_sets, iterations):
+    return [sharding.task_cost(objects[o].shape[-2] * objects[o].shape[-1], len(psf_sets[p]), iterations)
+            for o, p, _ in tasks]
+
+
+def run_tasks(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype='f32', device=0,
+              max_frames_per_plan=256):
+    """Run tasks on one GPU.  Returns a list of (ny, nx) estimates in task order."""
+    out = [None] * len(tasks)
+    groups = {}
+    for idx, (o, p, s) in enumerate(tasks):
+        shape = objects[o].shape[-2:]
+        groups.setdefault((p, shape, s), []).append(idx)
+    for (p, shape, s), idxs in groups.items():
+        for start in range(0, len(idxs), max_frames_per_plan):
+            part = idxs[start:start + max_frames_per_plan]
+            frames = np.stack([np.asarray(objects[tasks[i][0]], dtype=np.float64).reshape(shape) for i in part])
+            plan = DeconvPlan(psf_sets[p], len(part), shape[0], shape[1], dtype=dtype, device=device)
+            plan.set_object(frames, total_brightness)
+            plan.simulate(seed=s, rng=RNG_PHILOX)
+            plan.iterate(iterations)
+            est = plan.estimate()
+            for k, i in enumerate(part):
+                out[i] = est[k]
+            del plan
+    return out
+
+
+def figure_2_sweep(objects, psf_sets, seeds, iterations, total_brightness=5e10, dtype='f32',
+                   device=0, dist=None):
+    """The sweep, sharded over the ranks of `dist` (an initialised torch.distributed
+    module) when given.  Objects must share one shape for the final gather.  Returns
+    (tasks, estimates[n_tasks, ny, nx]) on rank 0 and (tasks, None) elsewhere."""
+    tasks = make_tasks(objects, psf_sets, seeds)
+    costs = task_costs(tasks, objects, psf_sets, iterations)
+
+    def run_local(mine):
+        return np.stack(run_tasks(mine, objects, psf_sets, iterations, total_brightness, dtype, device))
+    if dist is None:
+        return tasks, run_local(tasks)
+    shapes = {tuple(objects[o].shape[-2:]) for o, _, _ in tasks}
+    if len(shapes) != 1:
+        raise ValueError('a sharded sweep gathers one stack: all objects must share a shape')
+    return tasks, sharding.run_sharded(tasks, costs, run_local, dist)

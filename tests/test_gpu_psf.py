@@ -137,3 +137,46 @@ def test_error_behaviour(st):
     with pytest.raises(AssertionError):
         st.Deconvolver([np.ones((1, 3, 3))], verbose=False).create_data_from_object(
             np.ones((1, 4, 4), dtype=np.float32))             # ref:503
+
+
+def test_rotate_matches_reference_psf_sets(st, golden):
+    """rotate (line_sted_figure_2.py:264-272) on the device: general angles against
+    the CPU oracle, and the complete figure-2 PSF sets (tune_psf x2, fine psf_report x2,
+    normalisation, rotation) against the reference's own (G8)."""
+    from rescan_line_sted_amd import psf
+    rng = np.random.default_rng(5)
+    for shape in ((1, 23, 23), (1, 17, 30), (1, 107, 107)):
+        a = rng.random(shape)
+        for deg in (45, 60, 22.5, 135, 120, 0, 90):
+            assert max_rel(psf.rotate(a, deg), orc.rotate(a, deg)) < 1e-12, (shape, deg)
+    g3, g8 = golden('g3_tune_psf'), golden('g8_fig2_psfs')
+    for name in ('1p0x_ld', '1p5x_lr', '2p0x_lr'):
+        pr, lr, pe, le, nori, maxexc, resc = g3[name + '/inputs']
+        c = psf.psf_comparison_pair(pr, lr, pe, le, 'rescanned' if resc else 'descanned', int(nori),
+                                    max_excitation_brightness=float(maxexc))
+        assert max_rel(c['point_sted_psf'][0], g8[name + '/point_sted_psf'][0]) < 1e-6
+        assert len(c['line_sted_psfs']) == int(nori)
+        for a, b in zip(c['line_sted_psfs'], g8[name + '/line_sted_psfs']):
+            assert max_rel(a, b) < 1e-6
+
+
+def test_reduced_figure_2_sweep(golden):
+    """BASELINE config 4 in miniature: objects x PSF sets x seeds through sweep.py equals
+    the same frames run one plan at a time."""
+    from rescan_line_sted_amd import sweep, _lib
+    g8, objs = golden('g8_fig2_psfs'), golden('objects')
+    objects = {n: objs[n][0].astype(np.float64) for n in ('astronaut', 'lines', 'rings')}
+    psf_sets = {'1p5x_point': [g8['1p5x_lr/point_sted_psf'][0]],
+                '1p5x_line3': [p[None] for p in g8['1p5x_lr/line_sted_psfs'][:, 0]]}
+    tasks, est = sweep.figure_2_sweep(objects, psf_sets, seeds=(0, 7), iterations=4, dtype='f32')
+    assert len(tasks) == 12 and est.shape == (12, 128, 128)
+    costs = sweep.task_costs(tasks, objects, psf_sets, 4)
+    assert max(costs) == 3 * min(costs)                       # 3-view tasks weigh three point tasks
+    for i in (0, 5, 11):
+        o, p, s = tasks[i]
+        frames = [t for t in tasks if t[1] == p and t[2] == s]
+        plan = _lib.DeconvPlan(psf_sets[p], len(frames), 128, 128, dtype='f32')
+        plan.set_object(np.stack([objects[t[0]] for t in frames]), 5e10)
+        plan.simulate(seed=s)
+        plan.iterate(4)
+        assert np.array_equal(plan.estimate()[frames.index(tasks[i])], est[i])

@@ -136,3 +136,27 @@ def test_published_dose_table(golden):
         ref = dict(zip(keys, g[name + '/point']))
         assert abs(ref['excitation_dose'] - exc) < 0.06
         assert abs(ref['depletion_dose'] - dep) < 0.06
+
+
+def test_spline_rotate_restates_scipy():
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    for shape in ((23, 23), (17, 30), (107, 107)):
+        a = rng.random(shape)
+        for deg in (45, 60, 22.5, 135, 120, 90, 180, 1e-3):
+            ref = ndimage.rotate(a[None], angle=deg, axes=(1, 2), reshape=False)[0]
+            assert np.abs(orc.spline_rotate(a, deg) - ref).max() < 1e-12, (shape, deg)
+
+
+@pytest.mark.parametrize('name', ['1p0x_ld', '1p5x_lr', '2p0x_lr'])
+def test_g8_fig2_psf_sets(golden, name):
+    """psf_comparison_pair (tune_psf x2, fine psf_report x2, normalisation, rotation)
+    against the PSF sets the reference's figure-2 script produced."""
+    g3, g8 = golden('g3_tune_psf'), golden('g8_fig2_psfs')
+    pr, lr, pe, le, nori, maxexc, resc = g3[name + '/inputs']
+    c = orc.psf_comparison_pair(pr, lr, pe, le, 'rescanned' if resc else 'descanned', int(nori),
+                                max_excitation_brightness=maxexc)
+    assert max_rel(c['point_sted_psf'][0], g8[name + '/point_sted_psf'][0]) < 1e-6
+    assert len(c['line_sted_psfs']) == int(nori)
+    for a, b in zip(c['line_sted_psfs'], g8[name + '/line_sted_psfs']):
+        assert max_rel(a, b) < 1e-6                # tune_psf agrees to ~1e-8; see test_g3_tune_psf
