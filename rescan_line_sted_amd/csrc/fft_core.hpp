@@ -348,20 +348,20 @@ RL_HD cx<T> tail_dft8(cx<T> x, int lane, Sync& sync) {
     const bool b2 = (p & 4) != 0, b1 = (p & 2) != 0, b0 = (p & 1) != 0;
     cx<T> o;
     if constexpr (!DIT) {
-        o = mk<T>(sync.shfl_xor(x.re, 32), sync.shfl_xor(x.im, 32));
+        o = mk<T>(sync.template shfl_xor<32>(x.re), sync.template shfl_xor<32>(x.im));
         x = b2 ? mul_w8<INV>(o - x, p & 3) : x + o;
-        o = mk<T>(sync.shfl_xor(x.re, 16), sync.shfl_xor(x.im, 16));
+        o = mk<T>(sync.template shfl_xor<16>(x.re), sync.template shfl_xor<16>(x.im));
         x = b1 ? (b0 ? rot90<INV>(o - x) : o - x) : x + o;
-        o = mk<T>(sync.shfl_xor(x.re, 8), sync.shfl_xor(x.im, 8));
+        o = mk<T>(sync.template shfl_xor<8>(x.re), sync.template shfl_xor<8>(x.im));
         x = b0 ? o - x : x + o;
     } else {
-        o = mk<T>(sync.shfl_xor(x.re, 8), sync.shfl_xor(x.im, 8));
+        o = mk<T>(sync.template shfl_xor<8>(x.re), sync.template shfl_xor<8>(x.im));
         x = b0 ? o - x : x + o;
         if (b1 && b0) x = rot90<INV>(x);
-        o = mk<T>(sync.shfl_xor(x.re, 16), sync.shfl_xor(x.im, 16));
+        o = mk<T>(sync.template shfl_xor<16>(x.re), sync.template shfl_xor<16>(x.im));
         x = b1 ? o - x : x + o;
         if (b2) x = mul_w8<INV>(x, p & 3);
-        o = mk<T>(sync.shfl_xor(x.re, 32), sync.shfl_xor(x.im, 32));
+        o = mk<T>(sync.template shfl_xor<32>(x.re), sync.template shfl_xor<32>(x.im));
         x = b2 ? o - x : x + o;
     }
     return x;

@@ -25,14 +25,16 @@ struct EmuSync {
     int lane;
     void wg() const { pthread_barrier_wait(bar); }
     void wave() const { pthread_barrier_wait(wave_bar); }
-    double shfl_xor(double v, int mask) const {
+    template <int MASK>
+    double shfl_xor(double v) const {
         xchg[lane] = v;
         pthread_barrier_wait(wave_bar);
-        const double o = xchg[lane ^ mask];
+        const double o = xchg[lane ^ MASK];
         pthread_barrier_wait(wave_bar);
         return o;
     }
-    float shfl_xor(float v, int mask) const { return (float)shfl_xor((double)v, mask); }
+    template <int MASK>
+    float shfl_xor(float v) const { return (float)shfl_xor<MASK>((double)v); }
 };
 
 template <class Body>
