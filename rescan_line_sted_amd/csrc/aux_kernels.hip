@@ -98,6 +98,41 @@ __global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ 
     }
 }
 
+// ---- host <-> plan staging: float64 host arrays are converted on the device -----------
+// per-frame sums of a float64 stack [frames][n] (one workgroup per frame, wavefront shuffles)
+__global__ void __launch_bounds__(1024) k_frame_sums(const double* __restrict__ x, size_t n, double* __restrict__ sums) {
+    __shared__ double part[16];
+    const double* f = x + (size_t)blockIdx.x * n;
+    double v = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) v += f[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        v = threadIdx.x < (blockDim.x >> 6) ? part[threadIdx.x] : 0.0;
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) sums[blockIdx.x] = v;
+    }
+}
+
+// dst[f][i] = (T)(src[f][i] * (target[f] / sums[f]))   (target == nullptr: plain conversion)
+template <typename T>
+__global__ void k_scale_convert(const double* __restrict__ src, T* __restrict__ dst, size_t n, size_t frames,
+                                const double* __restrict__ target, const double* __restrict__ sums) {
+    const size_t total = n * frames;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n;
+        const double k = target ? target[f] / sums[f] : 1.0;
+        dst[i] = (T)(src[i] * k);
+    }
+}
+
+template <typename T>
+__global__ void k_to_f64(const T* __restrict__ src, double* __restrict__ dst, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (double)src[i];
+}
+
 static unsigned blocks_for(size_t n, unsigned block) {
     size_t b = (n + block - 1) / block;
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));   // grid-stride beyond 2048 workgroups
@@ -137,6 +172,22 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
         k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, seed, rng_kind, list, seg_cap, counts);
         if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, seed, list, seg_cap, counts);
     }
+    return hipGetLastError();
+}
+
+hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
+                             double* sums, hipStream_t s) {
+    if (target) k_frame_sums<<<(unsigned)frames, 1024, 0, s>>>(src, n, sums);
+    const unsigned g = blocks_for(n * frames, 256);
+    if (dtype == DT_F32) k_scale_convert<float><<<g, 256, 0, s>>>(src, (float*)dst, n, frames, target, sums);
+    else k_scale_convert<double><<<g, 256, 0, s>>>(src, (double*)dst, n, frames, target, sums);
+    return hipGetLastError();
+}
+
+hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s) {
+    const unsigned g = blocks_for(total, 256);
+    if (dtype == DT_F32) k_to_f64<float><<<g, 256, 0, s>>>((const float*)src, dst, total);
+    else k_to_f64<double><<<g, 256, 0, s>>>((const double*)src, dst, total);
     return hipGetLastError();
 }
 

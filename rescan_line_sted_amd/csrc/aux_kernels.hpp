@@ -15,4 +15,9 @@ hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev
 size_t aux_poisson_workspace_bytes(size_t total_pixels);
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img,
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s);
+// float64 stack [frames][n] (device) -> plan dtype, each frame scaled to sum target[f]
+// (target / sums: device arrays of `frames` doubles; target == nullptr: no scaling)
+hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
+                             double* sums, hipStream_t s);
+hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s);
 }  // namespace rl

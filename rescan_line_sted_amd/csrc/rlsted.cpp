@@ -83,7 +83,6 @@ struct rl_deconv {
     long iterations = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_iter_ms = 0, last_sim_ms = 0;
-    std::vector<double> stage;   // host staging
 
     size_t n_img() const { return (size_t)ny * nx; }
     size_t n_spec() const { return (size_t)ny * pitch; }
@@ -154,28 +153,51 @@ struct rl_deconv {
                                : row_t<double>(mode, gy, spec_in, spec_out, src, dst, nrm, scale, views);
     }
 
-    // host double [n] -> device dtype
-    int upload(const double* src, void* dst, size_t n) {
-        if (dtype == RL_F64) {
-            HIP_TRY(hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        } else {
-            std::vector<float> f(n);
-            for (size_t i = 0; i < n; ++i) f[i] = (float)src[i];
-            HIP_TRY(hipMemcpyAsync(dst, f.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // Host float64 <-> plan dtype.  The conversion (and the brightness scaling) runs on the
+    // device: the host array goes over PCIe as it is, in slices of at most kStageElems
+    // doubles, through a device staging buffer.
+    static constexpr size_t kStageElems = (size_t)16 << 20;   // 128 MiB of float64
+    double* stage_dev = nullptr;   // [kStageElems] + per-frame sums / targets
+    double* stage_aux = nullptr;   // [2 * B]
+    int ensure_stage() {
+        if (stage_dev) return RL_OK;
+        HIP_TRY(hipMalloc((void**)&stage_dev, kStageElems * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&stage_aux, 2 * (size_t)B * sizeof(double)));
+        bytes += kStageElems * sizeof(double);
+        return RL_OK;
+    }
+    // images: `count` images of n_img() pixels; target (host, per image) may be nullptr
+    int upload_images(const double* src, void* dst, size_t count, const double* target) {
+        RL_TRY(ensure_stage());
+        const size_t n = n_img();
+        if (n > kStageElems) return fail(RL_ERR_UNSUPPORTED, "image larger than the staging buffer");
+        const size_t per = kStageElems / n;
+        if (target) HIP_TRY(hipMemcpyAsync(stage_aux, target, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        for (size_t f0 = 0; f0 < count; f0 += per) {
+            const size_t nf = f0 + per <= count ? per : count - f0;
+            HIP_TRY(hipMemcpyAsync(stage_dev, src + f0 * n, nf * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(aux_scale_convert(dtype, stage_dev, (char*)dst + f0 * n * esize(dtype), n, nf,
+                                      target ? stage_aux + f0 : nullptr, stage_aux + B + f0, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next slice
         }
         return RL_OK;
+    }
+    int upload(const double* src, void* dst, size_t n) {
+        if (n % n_img() == 0) return upload_images(src, dst, n / n_img(), nullptr);
+        return fail(RL_ERR_INVALID, "internal: upload of a partial image");
     }
     int download(const void* src, double* dst, size_t n) {
         if (dtype == RL_F64) {
             HIP_TRY(hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
-        } else {
-            std::vector<float> f(n);
-            HIP_TRY(hipMemcpyAsync(f.data(), src, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            return RL_OK;
+        }
+        RL_TRY(ensure_stage());
+        for (size_t o = 0; o < n; o += kStageElems) {
+            const size_t m = o + kStageElems <= n ? kStageElems : n - o;
+            HIP_TRY(aux_to_f64(dtype, (const char*)src + o * esize(dtype), stage_dev, m, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(dst + o, stage_dev, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
-            for (size_t i = 0; i < n; ++i) dst[i] = (double)f[i];
         }
         return RL_OK;
     }
@@ -311,7 +333,8 @@ int rl_ctx_synchronize(rl_ctx* c) {
 int rl_deconv_destroy(rl_deconv* h) {
     if (!h) return RL_OK;
     hipSetDevice(h->ctx->device);
-    void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch};
+    void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
+                    h->stage_dev, h->stage_aux};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -419,21 +442,8 @@ int rl_deconv_info(const rl_deconv* h, int* ly, int* lx, int* pitch, size_t* dev
 int rl_deconv_set_object(rl_deconv* h, const double* obj, const double* total_brightness) {
     if (!h || !obj) return fail(RL_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(h->ctx->device));
-    const size_t n = h->n_img();
-    h->stage.resize((size_t)h->B * n);
-    for (int f = 0; f < h->B; ++f) {
-        const double* src = obj + (size_t)f * n;
-        double* dst = h->stage.data() + (size_t)f * n;
-        if (total_brightness) {                       // :505-506  obj *= total_brightness / obj.sum()
-            double s = 0.0;
-            for (size_t i = 0; i < n; ++i) s += src[i];
-            const double k = total_brightness[f] / s;
-            for (size_t i = 0; i < n; ++i) dst[i] = src[i] * k;
-        } else {
-            std::memcpy(dst, src, n * 8);
-        }
-    }
-    RL_TRY(h->upload(h->stage.data(), h->obj, (size_t)h->B * n));
+    // :505-506  obj *= total_brightness / obj.sum(), per frame, on the device
+    RL_TRY(h->upload_images(obj, h->obj, (size_t)h->B, total_brightness));
     HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
     RL_TRY(h->forward_object());
     HIP_TRY(hipEventRecord(h->ev1, h->ctx->stream));
