@@ -202,17 +202,25 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 
     if constexpr (MODE == COL_PER_IMAGE) {
         const int frame = by / p.V, view = by % p.V;
+        rl_stamp(sync, 0);
         load_tile(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img);
+        rl_stamp(sync, 1);
         sync.wg();
+        rl_stamp(sync, 2);
         if (colok) {
             cx<T> v[VMAX];
             cx<T> tl = mk<T>((T)0, (T)0);
             run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+            rl_stamp(sync, 3);
             multiply(v, tl, view);
+            rl_stamp(sync, 4);
             inverse_to_lds(v, tl, p.tw);
         }
+        rl_stamp(sync, 5);
         sync.wg();
+        rl_stamp(sync, 6);
         store_tile(p.out + (size_t)by * img);
+        rl_stamp(sync, 7);
     } else if constexpr (MODE == COL_H_MULTI) {
         load_tile(p.in + (size_t)by * img);
         sync.wg();
@@ -322,6 +330,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     // current estimate for ROW_UPDATE).
     constexpr bool PREFETCH = (MODE == ROW_RATIO || MODE == ROW_UPDATE);
     cx<T> pre[PREFETCH ? NB * R : 1];
+    rl_stamp(sync, 0);
     if constexpr (PREFETCH) {
         const T* __restrict__ src = (MODE == ROW_RATIO ? p.src : p.dst) + (size_t)by * rimg;
 #pragma unroll
@@ -371,13 +380,38 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 }
             }
             fft_sync<Cfg>(sync);
+            rl_stamp(sync, 1);   // spectrum rows have arrived and are packed in LDS
             run_passes<Cfg, true, 0, false>(v, tl, t, view_lds, p.tw, sync);
+            rl_stamp(sync, 2);
             if constexpr (MULTI && !ONEV) {
 #pragma unroll
                 for (int s = 0; s < NB * R; ++s) {
                     acc[s].re += v[s].re > (T)0 ? v[s].re : (T)0;
                     acc[s].im += v[s].im > (T)0 ? v[s].im : (T)0;
                 }
+            }
+        }
+    }
+
+    // ROW_UPDATE / ROW_ADJ: every normaliser value is requested before the first store of the
+    // pointwise stage.  (vmcnt retires in order: a load issued behind a store cannot be
+    // waited for without waiting for that store, and the compiler may not move the loads up
+    // across stores through a pointer it cannot prove distinct -- left interleaved, the
+    // stage is 2*NB*R serial memory round trips.)
+    constexpr bool NORMED = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
+    cx<T> nrm[NORMED ? NB * R : 1];
+    if constexpr (NORMED) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int j = t + nb * TT;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = j + r * NBF;
+                const bool inx = (j < NBF) && (i < p.nx);
+                cx<T> m = mk<T>((T)1, (T)1);
+                if (p.norm && inx && ok0) m.re = p.norm[(size_t)r0 * p.nx + i];
+                if (p.norm && inx && ok1) m.im = p.norm[(size_t)r1 * p.nx + i];
+                nrm[nb * R + r] = m;
             }
         }
     }
@@ -409,12 +443,12 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    z.re = pre[PREFETCH ? s : 0].re * rl_div(a.re, p.norm[o]);
+                    z.re = pre[PREFETCH ? s : 0].re * rl_div(a.re, nrm[NORMED ? s : 0].re);
                     est[o] = z.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    z.im = pre[PREFETCH ? s : 0].im * rl_div(a.im, p.norm[o]);
+                    z.im = pre[PREFETCH ? s : 0].im * rl_div(a.im, nrm[NORMED ? s : 0].im);
                     est[o] = z.im;
                 }
             } else if constexpr (MODE == ROW_ADJ) {
@@ -422,19 +456,21 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    dst[o] = p.norm ? a.re / p.norm[o] : a.re;
+                    dst[o] = p.norm ? a.re / nrm[NORMED ? s : 0].re : a.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    dst[o] = p.norm ? a.im / p.norm[o] : a.im;
+                    dst[o] = p.norm ? a.im / nrm[NORMED ? s : 0].im : a.im;
                 }
             }
             v[s] = z;
         }
     }
 
+    rl_stamp(sync, 3);   // pointwise stage done (its operands have arrived)
     if constexpr (MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE) {
         run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
+        rl_stamp(sync, 4);
         // natural-order spectrum to LDS, then split it into the two rows' half spectra
         using FL = PassInfo<Cfg, false, NP - 1>;
         fft_sync<Cfg>(sync);
@@ -459,6 +495,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (ok1) so[(size_t)r1 * p.pitch + k] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
             }
         }
+        rl_stamp(sync, 5);
     }
 }
 

@@ -313,6 +313,15 @@ struct WavePrivate {
     static constexpr bool value = (Cfg::T == 64);
 };
 
+// Optional phase stamps: a Sync policy that has stamp(int) (tools/stamp_probe.hip) gets
+// called at the phase boundaries of the kernel bodies; for every other policy this is nothing.
+template <class Sync>
+RL_HD auto rl_stamp_impl(Sync& s, int k, int) -> decltype(s.stamp(k), void()) { s.stamp(k); }
+template <class Sync>
+RL_HD void rl_stamp_impl(Sync&, int, long) {}
+template <class Sync>
+RL_HD void rl_stamp(Sync& s, int k) { rl_stamp_impl(s, k, 0); }
+
 template <class Cfg, class Sync>
 RL_HD void fft_sync(Sync& sync) {
     if constexpr (WavePrivate<Cfg>::value) sync.wave();

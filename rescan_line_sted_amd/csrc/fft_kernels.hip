@@ -5,6 +5,7 @@
 #include "kernel_table.hpp"
 #include "conv_kernels.hpp"
 #include "fft_configs.hpp"
+#include "dev_sync.hpp"
 
 // waves/SIMD requested for the f32 ROW_RATIO kernel (needs <= 96 VGPRs, which it has
 // within 2 registers; the other modes spill under that bound and are left alone)
@@ -26,46 +27,6 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 #define RL_CAT_(a, b) a##b
 #define RL_CAT(a, b) RL_CAT_(a, b)
 #define RL_TABLE_FN RL_CAT(table_, RL_CFG_L)
-
-struct DevSync {
-    __device__ __forceinline__ void wg() const { __syncthreads(); }
-    // One wave exchanging data with itself through LDS: the hardware completes a
-    // wave's LDS operations in issue order, so only compiler reordering has to be
-    // prevented (wavefront-scope fences emit no instructions).
-    __device__ __forceinline__ void wave() const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    // value held by lane (this lane ^ MASK), MASK = 8 / 16 / 32; all 64 lanes must be active.
-    // VALU cross-lane moves of gfx950 (no LDS round trip, unlike ds_bpermute):
-    //   ^32  v_permlane32_swap: swaps the upper half of one register with the lower half of another
-    //   ^16  v_permlane16_swap: swaps the odd 16-lane rows of one with the even rows of another
-    //   ^8   DPP row_ror:8 (rotate the 16-lane row by half its length)
-    template <int MASK>
-    __device__ __forceinline__ unsigned shfl_xor_u32(unsigned u) const {
-        if constexpr (MASK == 32) {
-            auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            return (threadIdx.x & 32) ? r[0] : r[1];
-        } else if constexpr (MASK == 16) {
-            auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-            return (threadIdx.x & 16) ? r[0] : r[1];
-        } else {
-            static_assert(MASK == 8, "unsupported exchange distance");
-            return (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false);
-        }
-    }
-    template <int MASK>
-    __device__ __forceinline__ float shfl_xor(float v) const {
-        return __uint_as_float(shfl_xor_u32<MASK>(__float_as_uint(v)));
-    }
-    template <int MASK>
-    __device__ __forceinline__ double shfl_xor(double v) const {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        const unsigned lo = shfl_xor_u32<MASK>((unsigned)b), hi = shfl_xor_u32<MASK>((unsigned)(b >> 32));
-        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-    }
-};
 
 // NOTE: the transform length is a template parameter of the kernels so that the
 // kernels of different lengths (built in separate translation units) have
