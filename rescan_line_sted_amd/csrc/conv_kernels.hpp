@@ -49,6 +49,7 @@ struct ColParams {
     int V;                  // views per frame; blockIdx.y = frame*V + view
     int in_sb, in_sv;       // COL_PER_IMAGE: input image index = frame*in_sb + view*in_sv
     int mode;               // ColMode (wave-private column kernel only; others: per image)
+    int images;             // streaming kernel: output images covered by the launch (grid.y of the tiled kernel)
 };
 
 template <class Cfg, int C, typename T, class Sync>
@@ -195,7 +196,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
             const int j = lane + nb * 64;
             if (j < IL::NBF) {
 #pragma unroll
-                for (int r = 0; r < IL::R; ++r) view_lds.at(j + r * IL::NBF) = v[nb * IL::R + r];
+                for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, lds_pad(j), r) = v[nb * IL::R + r];
             }
         }
     };
@@ -301,6 +302,7 @@ struct RowParams {
     const T* scale;         // ROW_FWD: per-frame multiplier or nullptr
     const cx<T>* tw;        // [Lx]
     int ny, nx, pitch, V;
+    int frames;             // streaming kernels: images covered by the launch (grid.y of the tiled kernels)
 };
 
 // ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.
@@ -480,7 +482,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             const int j = t + nb * TT;
             if (j < FL::NBF) {
 #pragma unroll
-                for (int r = 0; r < FL::R; ++r) view_lds.at(j + r * FL::NBF) = v[nb * FL::R + r];
+                for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, lds_pad(j), r) = v[nb * FL::R + r];
             }
         }
         fft_sync<Cfg>(sync);
@@ -493,6 +495,319 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
                 if (ok0) so[(size_t)r0 * p.pitch + k] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
                 if (ok1) so[(size_t)r1 * p.pitch + k] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+            }
+        }
+        rl_stamp(sync, 5);
+    }
+}
+
+// ============================================================================
+// Streaming variants of the Richardson-Lucy kernels (wave-private transform
+// lengths, one view): persistent workgroups walk the work items, the twiddle
+// table lives in LDS, and the operands of item i+1 are requested while item i
+// is being transformed.
+//
+// Why: stamps (tools/stamp_probe.hip) show a wave of the tiled kernels idle for
+// ~30 % of its life in the initial HBM round trip, and the occupancy (4-5 waves
+// per SIMD) cannot cover it.  Twiddles must leave global memory for this to work:
+// vmcnt retires in order, so waiting for a twiddle load issued behind the
+// prefetch would wait for the prefetch too.
+// ============================================================================
+template <class Cfg>
+struct StreamTw {
+    static constexpr int COUNT = PassTw<Cfg, false, 0>::TOTAL;   // complex entries, both directions
+};
+
+// Opaque to the optimiser: keeps loop-invariant LDS twiddle reads (and the address
+// arithmetic behind them) inside the item loop instead of in ~60 hoisted registers.
+RL_HD int stream_launder(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
+// Same for a per-lane value (the thread index): everything derived from it -- a dozen 64-bit
+// addresses per stage -- is then recomputed per item (a few VALU ops) instead of living in
+// registers across the whole loop body.
+RL_HD int stream_launder_lane(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
+// Work item order of a persistent grid.  Workgroups are dealt round-robin over the 8 XCDs
+// (wg % 8); each XCD gets a contiguous range of items so that neighbouring tiles -- which share
+// 128-B lines -- meet in one L2.  Any order is correct.
+struct StreamOrder {
+    int total, nwg, wg;
+    bool xcd;
+    RL_HD StreamOrder(int total_, int nwg_, int wg_) : total(total_), nwg(nwg_), wg(wg_), xcd(total_ % 8 == 0 && nwg_ % 8 == 0) {}
+    RL_HD int item(int k) const {   // k-th item of this workgroup, or -1
+        if (xcd) {
+            const int per = total / 8, idx = wg / 8 + k * (nwg / 8);
+            return idx < per ? (wg % 8) * per + idx : -1;
+        }
+        const long lin = (long)wg + (long)k * nwg;
+        return lin < total ? (int)lin : -1;
+    }
+};
+
+// Column pass, COL_PER_IMAGE semantics, one workgroup of C waves per tile of C spectrum columns.
+template <class Cfg, int C, typename T, class Sync>
+RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
+    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    constexpr int NT = 64 * C;
+    static_assert((L * C) % NT == 0, "tile must divide evenly over the workgroup");
+    constexpr int NLD = (L * C) / NT;
+    using FL = PassInfo<Cfg, false, NP - 1>;
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
+    const int w = tid / 64, lane = tid % 64;
+    const size_t img = (size_t)p.ny * p.pitch;
+    LdsView<T, 1> view_lds{lds + w * LP};
+
+    for (int i = tid; i < StreamTw<Cfg>::COUNT; i += NT) lds[C * LP + i] = p.tw[i];
+
+    const int tiles = (p.kx + C - 1) / C;
+    const StreamOrder order(p.images * tiles, nwg, wg);
+    cx<T> x[NLD];
+    // tile element e = tid + it*NT  <->  (row = e / C, column c = e % C)
+    auto request = [&](int lin, int tid) {
+        const int by = lin / tiles, col0 = (lin % tiles) * C;
+        const int frame = by / p.V, view = by % p.V;
+        const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
+        // Unconditional loads from clamped (always valid) addresses, zero selected at the use:
+        // a load under a lane-dependent branch makes every later counted s_waitcnt vmcnt(N)
+        // collapse to vmcnt(0), which would drain the prefetch at its first neighbour's use.
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const int row = e / C, c = e % C;
+            const int rr = row < p.ny ? row : p.ny - 1, cc = col0 + c < p.pitch ? col0 + c : p.pitch - 1;
+            x[it] = in[(size_t)rr * p.pitch + cc];   // zero selected where it is consumed, not here:
+        }                                            // a select right behind the load would wait for it
+    };
+    int lin = order.item(0);
+    if (lin >= 0) request(lin, tid);
+    sync.wg();   // twiddles are in LDS
+    const int tid0 = tid;
+    for (int k = 0; lin >= 0; ++k) {
+        const cx<T>* tw = lds + stream_launder(C * LP);
+        const int tid = stream_launder_lane(tid0), w = tid / 64, lane = tid % 64;
+        LdsView<T, 1> view_lds{lds + w * LP};
+        const int by = lin / tiles, col0 = (lin % tiles) * C, col = col0 + w;
+        const bool colok = col < p.kx;
+        const int view = by % p.V;
+        rl_stamp(sync, 0);
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const bool ok = e / C < p.ny && col0 + e % C < p.kx;
+            lds[(e % C) * LP + lds_pad(e / C)] = mk<T>(ok ? x[it].re : (T)0, ok ? x[it].im : (T)0);
+        }
+        rl_stamp(sync, 1);
+        sync.wg();
+        rl_stamp(sync, 2);
+        const int next = order.item(k + 1);
+        if (colok) {
+            cx<T> v[VMAX];
+            cx<T> tl = mk<T>((T)0, (T)0);
+            run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw, sync);
+            rl_stamp(sync, 3);
+            {   // v, tl *= psf_hat[view] column (register layout of the last forward pass)
+                const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
+#pragma unroll
+                for (int nb = 0; nb < FL::NBM; ++nb) {
+                    const int j = lane + nb * 64;
+                    if (j < FL::NBF) {
+#pragma unroll
+                        for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[j + r * FL::NBF]);
+                    }
+                }
+                if constexpr (FL::TAIL) tl = cmul(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
+            }
+            rl_stamp(sync, 4);
+            request(next >= 0 ? next : lin, tid);   // in flight during the inverse transform and the tile store
+            run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw, sync);
+            sync.wave();   // last pass' LDS reads are done before the column is overwritten
+#pragma unroll
+            for (int nb = 0; nb < IL::NB; ++nb) {
+                const int j = lane + nb * 64;
+                if (j < IL::NBF) {
+#pragma unroll
+                    for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, lds_pad(j), r) = v[nb * IL::R + r];
+                }
+            }
+        } else {
+            request(next >= 0 ? next : lin, tid);
+        }
+        rl_stamp(sync, 5);
+        sync.wg();
+        rl_stamp(sync, 6);
+        {
+            cx<T>* __restrict__ out = p.out + (size_t)by * img;
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int e = tid + it * NT;
+                const int row = e / C, c = e % C;
+                if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+            }
+        }
+        rl_stamp(sync, 7);
+        lin = next;
+        if (lin >= 0) sync.wg();   // the tile is read out before the next one is written
+    }
+}
+
+// Row pass, ROW_RATIO or ROW_UPDATE with one view; every wave walks its own row pairs
+// (no workgroup barrier after the twiddle copy).
+//
+// Addressing: the row pair is a property of the wave, so all bases are scalar (rl_uniform) and a
+// lane adds its own small offset: loads and stores are `scalar base + lane offset + immediate`.
+// Loads are unconditional and unclamped: lanes past the end of a row read the following bytes
+// (the plan allocates RL_STREAM_SLACK bytes behind every buffer for the very last row) and the
+// values are discarded where they would be used.  A load under a lane-dependent branch would make
+// every later counted `s_waitcnt vmcnt(N)` collapse to vmcnt(0) and drain the prefetch.
+#ifndef RL_STREAM_LAUNDER_LDS
+#define RL_STREAM_LAUNDER_LDS 1   // 1: LDS lane addresses are recomputed per item (fewer registers, more VALU)
+#endif
+constexpr size_t RL_STREAM_SLACK = 16384;   // >= (L - nx) elements of any dtype for the wave-private lengths
+
+template <class Cfg, int Q, int MODE, typename T, class Sync>
+RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
+    static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "streaming row pass: RL modes only");
+    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    using F0 = PassInfo<Cfg, false, 0>;
+    using FL = PassInfo<Cfg, false, NP - 1>;
+    static_assert(IL::R == F0::R && IL::NB == F0::NB, "inverse must end on the forward's first radix");
+    static_assert(!F0::TAIL, "the pass that touches the images must be lane-local");
+    constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
+    constexpr int NPK = (L / 2 + 64) / 64;   // ceil((L/2 + 1) / 64)
+    static_assert((size_t)(NB * 64 + (R - 1) * NBF) * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");
+    const int q = rl_uniform(tid / 64);
+    const unsigned t = (unsigned)(tid % 64);
+    const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
+    LdsView<T, 1> view_lds{lds + q * LP};
+
+    for (int i = tid; i < StreamTw<Cfg>::COUNT; i += 64 * Q) lds[Q * LP + i] = p.tw[i];
+
+    const int pairs = (p.ny + 1) / 2;
+    const int total = p.frames * pairs, stride = nwg * Q;
+    cx<T> A[NPK], B[NPK];
+    auto request = [&](int item) {   // the two half spectra of row pair `item` (scalar)
+        const int by = item / pairs, r0 = 2 * (item % pairs);
+        const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * simg + (size_t)r0 * p.pitch;
+        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? p.pitch : 0);   // one-row pair: row r0 again, zeroed at the use
+#pragma unroll
+        for (int it = 0; it < NPK; ++it) {
+            A[it] = sa[t + it * 64];
+            B[it] = sb[t + it * 64];
+        }
+    };
+    int item = wg * Q + q;
+    if (item < total) request(item);
+    sync.wg();   // twiddles are in LDS; from here on the waves never meet again
+    for (; item < total; item += stride) {
+        const cx<T>* tw = lds + stream_launder(Q * LP);
+        const int tl_ = RL_STREAM_LAUNDER_LDS ? stream_launder_lane((int)t) : (int)t;   // lane index for LDS addressing
+        const int by = item / pairs, r0 = 2 * (item % pairs), r1 = r0 + 1;
+        const bool ok1 = r1 < p.ny;
+        rl_stamp(sync, 0);
+        // operands of the pointwise stage: measurement (ROW_RATIO) / current estimate (ROW_UPDATE)
+        cx<T> pre[NB * R];
+        T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * p.nx;
+        T* __restrict__ const est1 = est0 + (ok1 ? p.nx : 0);
+        {
+            const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * p.nx : est0;
+            const T* __restrict__ s1 = s0 + (ok1 ? p.nx : 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < R; ++r) pre[nb * R + r] = mk<T>(s0[t + (nb * 64 + r * NBF)], s1[t + (nb * 64 + r * NBF)]);
+        }
+        cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
+        if constexpr (MODE == ROW_UPDATE) {   // requested with the estimate, ahead of the inverse transform: behind it
+                                              // they would cost the pointwise stage an exposed L2 round trip
+            const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
+            const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
+        }
+        // pack the two half spectra into one Hermitian-free complex row
+        fft_sync<Cfg>(sync);   // LDS free
+#pragma unroll
+        for (int it = 0; it < NPK; ++it) {
+            const int kk = tl_ + it * 64;
+            if (kk <= L / 2) {
+                const cx<T> a = A[it], b = mk<T>(ok1 ? B[it].re : (T)0, ok1 ? B[it].im : (T)0);
+                view_lds.at(kk) = mk<T>(a.re - b.im, a.im + b.re);
+                if (kk > 0 && kk < L / 2) view_lds.at(L - kk) = mk<T>(a.re + b.im, b.re - a.im);
+            }
+        }
+        // lands while this item is transformed; unconditional (the last item re-requests itself) so
+        // that the waits of the pointwise stage can count past it
+        request(item + stride < total ? item + stride : item);
+        fft_sync<Cfg>(sync);
+        rl_stamp(sync, 1);
+        cx<T> v[VMAX];
+        cx<T> tl = mk<T>((T)0, (T)0);
+        run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
+        rl_stamp(sync, 2);
+
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int j = (int)t + nb * 64;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int s = nb * R + r;
+                const int i = j + r * NBF;
+                const bool inx = (j < NBF) && (i < p.nx);
+                cx<T> z = mk<T>((T)0, (T)0);
+                const T e0 = v[s].re > (T)0 ? v[s].re : (T)0, e1 = v[s].im > (T)0 ? v[s].im : (T)0;
+                if constexpr (MODE == ROW_RATIO) {
+                    z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
+                    z.im = inx && ok1 ? rl_div(pre[s].im, e1) : (T)0;
+                } else {
+                    z.re = inx ? pre[s].re * rl_div(e0, nrm[s].re) : (T)0;
+                    z.im = inx && ok1 ? pre[s].im * rl_div(e1, nrm[s].im) : (T)0;
+                    if (inx) est0[t + (nb * 64 + r * NBF)] = z.re;
+                    if (inx && ok1) est1[t + (nb * 64 + r * NBF)] = z.im;
+                }
+                v[s] = z;
+            }
+        }
+        rl_stamp(sync, 3);
+        run_passes<Cfg, false, 0, true>(v, tl, tl_, view_lds, tw, sync);
+        rl_stamp(sync, 4);
+        // natural-order spectrum to LDS, then split it into the two rows' half spectra
+        fft_sync<Cfg>(sync);
+        if constexpr (FL::TAIL) view_lds.at((64 + (tl_ & 7)) + bitrev3(tl_ >> 3) * FL::NBF) = tl;
+#pragma unroll
+        for (int nb = 0; nb < FL::NBM; ++nb) {
+            const int j = tl_ + nb * 64;
+            if (j < FL::NBF) {
+#pragma unroll
+                for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, lds_pad(j), r) = v[nb * FL::R + r];
+            }
+        }
+        fft_sync<Cfg>(sync);
+        cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
+        cx<T>* __restrict__ so1 = so0 + p.pitch;
+#pragma unroll
+        for (int it = 0; it < NPK; ++it) {
+            const int kk = tl_ + it * 64;
+            if (kk <= L / 2) {
+                const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
+                so0[t + it * 64] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
+                if (ok1) so1[t + it * 64] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
             }
         }
         rl_stamp(sync, 5);

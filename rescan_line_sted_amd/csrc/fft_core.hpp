@@ -201,6 +201,15 @@ template <typename T, int CS>
 struct LdsView {
     cx<T>* base;
     RL_HD cx<T>& at(int idx) const { return base[lds_pad(idx) * CS]; }
+    // Element idx0 + k*STEP, with the padded position of idx0 already known.  For a step that
+    // is a multiple of 8 the padding is linear, lds_pad(idx0 + k*STEP) = lds_pad(idx0) +
+    // k*(STEP + STEP/8): one lane address plus a compile-time offset that folds into the
+    // immediate field of the ds_read / ds_write, instead of shift + add per access.
+    template <int STEP>
+    RL_HD cx<T>& at_step(int idx0, int pad0, int k) const {
+        if constexpr (STEP % 8 == 0) return base[(pad0 + k * (STEP + STEP / 8)) * CS];
+        else return base[lds_pad(idx0 + k * STEP) * CS];
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -284,8 +293,13 @@ RL_HD void pass_store_lds(const cx<T>* v, int t, LdsView<T, CS> lds) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
             const int j0 = (j / PI::NS) * (PI::NS * R) + (j % PI::NS);
+            // NS == 1, R == 8: lds_pad(8j + r) = 9j + r
+            const int p0 = (PI::NS == 1 && R == 8) ? 9 * j : lds_pad(j0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) lds.at(j0 + r * PI::NS) = v[nb * R + r];
+            for (int r = 0; r < R; ++r) {
+                if constexpr (PI::NS == 1 && R == 8) lds.base[(p0 + r) * CS] = v[nb * R + r];
+                else lds.template at_step<PI::NS>(j0, p0, r) = v[nb * R + r];
+            }
         }
     }
 }
@@ -298,8 +312,9 @@ RL_HD void pass_load_lds(cx<T>* v, int t, LdsView<T, CS> lds) {
     for (int nb = 0; nb < PI::NBM; ++nb) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
+            const int p0 = lds_pad(j);
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[nb * R + r] = lds.at(j + r * PI::NBF);
+            for (int r = 0; r < R; ++r) v[nb * R + r] = lds.template at_step<PI::NBF>(j, p0, r);
         }
     }
 }
@@ -312,6 +327,17 @@ template <class Cfg>
 struct WavePrivate {
     static constexpr bool value = (Cfg::T == 64);
 };
+
+// A value that is the same in every lane of the wavefront, moved to a scalar register so that
+// everything derived from it (row / image base addresses) is scalar arithmetic and the memory
+// instructions take the `scalar base + 32-bit lane offset + immediate` form.
+RL_HD int rl_uniform(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return x;
+#endif
+}
 
 // Optional phase stamps: a Sync policy that has stamp(int) (tools/stamp_probe.hip) gets
 // called at the phase boundaries of the kernel bodies; for every other policy this is nothing.

@@ -64,6 +64,99 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (sizeof(T) == 4 && MODE 
     rowpass_body<typename CfgFor<L>::Cfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 
+// ---- streaming kernels (wave-private lengths): persistent workgroups, twiddles in LDS ----
+#ifndef RL_STREAM_Q32
+#define RL_STREAM_Q32 8
+#endif
+#ifndef RL_STREAM_Q64
+#define RL_STREAM_Q64 4
+#endif
+#ifndef RL_STREAM_ROW_MIN_WAVES
+#define RL_STREAM_ROW_MIN_WAVES 1
+#endif
+#ifndef RL_STREAM_COL_MIN_WAVES
+#define RL_STREAM_COL_MIN_WAVES 1
+#endif
+template <int L, int C, typename T>
+__global__ void __launch_bounds__(64 * C, sizeof(T) == 4 ? RL_STREAM_COL_MIN_WAVES : 1) k_colstream(const ColParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevSync s;
+    colstream_body<typename CfgFor<L>::Cfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<T>*>(smem), s);
+}
+template <int L, int Q, int MODE, typename T>
+__global__ void __launch_bounds__(64 * Q, sizeof(T) == 4 ? RL_STREAM_ROW_MIN_WAVES : 1) k_rowstream(const RowParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevSync s;
+    rowstream_body<typename CfgFor<L>::Cfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<T>*>(smem), s);
+}
+
+template <int N, typename T>
+static constexpr size_t stream_lds_bytes() {
+    return ((size_t)N * LdsLen<Cfg::L>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>);
+}
+
+// workgroups of `fn` that the device holds at once (0 on error), a multiple of 8 (one share per XCD)
+template <typename F>
+static int resident_workgroups(F* fn, int threads, size_t lds) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (lds > 65536 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) return 0;
+    const int n = per_cu * prop.multiProcessorCount;
+    return n >= 8 ? n / 8 * 8 : n;
+}
+
+template <int C, typename T>
+static hipError_t launch_col_stream_t(const void* params, hipStream_t s) {
+    if constexpr (WavePrivate<Cfg>::value) {
+        const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
+        constexpr size_t lds = stream_lds_bytes<C, T>();
+        static const int resident = resident_workgroups(k_colstream<RL_CFG_L, C, T>, 64 * C, lds);
+        if (resident < 1) return hipErrorLaunchFailure;
+        const long total = (long)p.images * ((p.kx + C - 1) / C);
+        if (total < 1) return hipSuccess;
+        long nwg = total < resident ? total : resident;
+        if (nwg >= 8 && total % 8 == 0) nwg = nwg / 8 * 8;
+        k_colstream<RL_CFG_L, C, T><<<dim3((unsigned)nwg), dim3(64 * C), lds, s>>>(p);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int Q, int MODE, typename T>
+static hipError_t launch_row_stream_m(const void* params, hipStream_t s) {
+    const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
+    constexpr size_t lds = stream_lds_bytes<Q, T>();
+    static const int resident = resident_workgroups(k_rowstream<RL_CFG_L, Q, MODE, T>, 64 * Q, lds);
+    if (resident < 1) return hipErrorLaunchFailure;
+    const long total = (long)p.frames * ((p.ny + 1) / 2);
+    if (total < 1) return hipSuccess;
+    const long need = (total + Q - 1) / Q;
+    k_rowstream<RL_CFG_L, Q, MODE, T><<<dim3((unsigned)(need < resident ? need : resident)), dim3(64 * Q), lds, s>>>(p);
+    return hipGetLastError();
+}
+
+template <int Q, typename T>
+static hipError_t launch_row_stream_t(int mode, const void* params, hipStream_t s) {
+    if constexpr (WavePrivate<Cfg>::value) {
+        if (mode == ROW_RATIO) return launch_row_stream_m<Q, ROW_RATIO, T>(params, s);
+        if (mode == ROW_UPDATE) return launch_row_stream_m<Q, ROW_UPDATE, T>(params, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_col_stream(int dtype, const void* params, hipStream_t s) {
+    return dtype == DT_F32 ? launch_col_stream_t<kC32, float>(params, s) : launch_col_stream_t<kC64, double>(params, s);
+}
+static hipError_t launch_row_stream(int dtype, int mode, const void* params, hipStream_t s) {
+    return dtype == DT_F32 ? launch_row_stream_t<RL_STREAM_Q32, float>(mode, params, s)
+                           : launch_row_stream_t<RL_STREAM_Q64, double>(mode, params, s);
+}
+
 template <int C, typename T>
 static constexpr size_t lds_bytes() {
     return (size_t)C * LdsLen<Cfg::L>::value * sizeof(cx<T>);
@@ -147,7 +240,9 @@ static hipError_t prepare() {
 
 const KernelTable* RL_TABLE_FN() {
     static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, WavePrivate<Cfg>::value ? 1 : 0,
-                                  PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>, launch_col, launch_row, prepare};
+                                  PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>, launch_col, launch_row, prepare,
+                                  WavePrivate<Cfg>::value ? launch_col_stream : nullptr,
+                                  WavePrivate<Cfg>::value ? launch_row_stream : nullptr};
     return &t;
 }
 

@@ -21,6 +21,11 @@ struct KernelTable {
     hipError_t (*launch_row)(int dtype, int mode, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);
     // one-time attribute setup (dynamic LDS above the default limit)
     hipError_t (*prepare)(void);
+    // Streaming (persistent, prefetching) Richardson-Lucy kernels for one view; nullptr when the
+    // length has none (transforms that are not wave private).  The grid is sized inside from the
+    // occupancy of the kernel; params carry the image count (ColParams::images / RowParams::frames).
+    hipError_t (*launch_col_stream)(int dtype, const void* params, hipStream_t s);
+    hipError_t (*launch_row_stream)(int dtype, int mode, const void* params, hipStream_t s);
 };
 
 const KernelTable* table_64();

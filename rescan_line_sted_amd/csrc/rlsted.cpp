@@ -78,6 +78,11 @@ struct rl_deconv {
     // H_t views summed before the inverse transforms (one clamp of the sum instead of one per
     // view, ref:587): default for f32 plans, off for f64 (faithful); RLSTED_FUSE_VIEWS=0/1 overrides
     bool fuse_views = false;
+    // persistent prefetching RL kernels where the length has them; bit mask: 1 column pass,
+    // 2 ROW_RATIO, 4 ROW_UPDATE.  Off by default: measured equal to the tiled kernels inside the
+    // chunked RL loop; RLSTED_STREAM=7 turns them on.
+    int streaming = 0;
+    bool inplace = true;     // single-view RL iterations entirely in spec_a (RLSTED_INPLACE=0: spec_a -> spec_b -> spec_a)
     bool est_ready = false;    // est holds a valid estimate
     bool spec_valid = false;   // spec_a holds rowFFT(est)
     long iterations = 0;
@@ -109,7 +114,11 @@ struct rl_deconv {
         }
         const int C = ty->C[dtype];
         const unsigned gx = (unsigned)((kx + C - 1) / C);
-        HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
+        p.images = (int)gy;
+        if ((streaming & 1) && p.mode == COL_PER_IMAGE && ty->launch_col_stream)
+            HIP_TRY(ty->launch_col_stream(dtype, &p, ctx->stream));
+        else
+            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess)
@@ -136,7 +145,11 @@ struct rl_deconv {
         p.ny = ny; p.nx = nx; p.pitch = pitch; p.V = views;
         const int Q = tx->Q[dtype];
         const unsigned pairs = (unsigned)((ny + 1) / 2);
-        HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
+        p.frames = (int)gy;
+        if (tx->launch_row_stream && (((streaming & 2) && mode == ROW_RATIO) || ((streaming & 4) && mode == ROW_UPDATE && views == 1)))
+            HIP_TRY(tx->launch_row_stream(dtype, mode, &p, ctx->stream));
+        else
+            HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess)
@@ -214,12 +227,16 @@ struct rl_deconv {
     // so the inter-kernel traffic is served on die instead of from HBM.
     char* off(void* base, size_t elems) const { return (char*)base + elems * esize(dtype); }
     int chunk_frames() const {
-        static const double budget_mb = getenv("RLSTED_CHUNK_MB") ? atof(getenv("RLSTED_CHUNK_MB")) : 288.0;
-        const double per_frame = ((1.0 + V) * 2.0 * n_spec() + (1.0 + V) * n_img()) * esize(dtype);
+        const double budget_mb = getenv("RLSTED_CHUNK_MB") ? atof(getenv("RLSTED_CHUNK_MB")) : 288.0;
+        const double specs = (V == 1 && inplace) ? 1.0 : 1.0 + V;   // spectra alive in an iteration
+        const double per_frame = (specs * 2.0 * n_spec() + (1.0 + V) * n_img()) * esize(dtype);
         int c = (int)(budget_mb * 1048576.0 / per_frame);
         if (c < 1) c = 1;
         if (c >= B) return B;
-        if (c > 8) c -= c % 8;
+        // equal slices (a short last slice would run its 4 launches per iteration nearly empty)
+        const int slices = (B + c - 1) / c;
+        c = (B + slices - 1) / slices;
+        if (c > 8) c = (c + 7) / 8 * 8;
         return c;
     }
     int start_estimate_chunk(int f0, int nf) {
@@ -231,6 +248,16 @@ struct rl_deconv {
     int iterate_chunk(int f0, int nf) {
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
+        if (V == 1 && inplace) {
+            // one view: every pass maps a spectrum onto itself (a column tile / a row pair is read
+            // completely before it is written), so the whole iteration runs in spec_a -- a third
+            // less working set per frame for the Infinity Cache, and stores that hit lines just read
+            RL_TRY(col(sa, sa, nf, true));
+            RL_TRY(row(ROW_RATIO, (unsigned)nf, sa, sa, off(meas, (size_t)f0 * n_img()), nullptr, nullptr));
+            RL_TRY(col(sa, sa, nf, false));
+            RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            return RL_OK;
+        }
         RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
         RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
         if (fuse_views && V > 1 && wave_private_y()) {
@@ -369,8 +396,11 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
         {&h->scratch, std::max(B * V * h->n_img() * es, aux_poisson_workspace_bytes(B * V * h->n_img()))}};   // also the Poisson work list
     for (const Req& r : reqs) {
-        HIP_TRY(hipMalloc(r.p, r.n));
-        h->bytes += r.n;
+        // RL_STREAM_SLACK: the streaming row kernels load whole 64-lane segments without clamping;
+        // lanes past the end of the last row of a buffer read (and discard) these bytes
+        HIP_TRY(hipMalloc(r.p, r.n + RL_STREAM_SLACK));
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(*r.p) + r.n, 0, RL_STREAM_SLACK, ctx->stream));
+        h->bytes += r.n + RL_STREAM_SLACK;
     }
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
@@ -418,6 +448,8 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     rl_deconv* h = new rl_deconv;
     h->ctx = ctx;
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
+    if (getenv("RLSTED_STREAM")) h->streaming = atoi(getenv("RLSTED_STREAM"));
+    if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     int r = deconv_build(h, psfs);
     if (r != RL_OK) {

@@ -65,6 +65,9 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
     for (auto& b : wbar) pthread_barrier_destroy(&b);
 }
 
+// > 0: run the streaming (persistent) bodies with that many workgroups where they apply
+static int g_stream_nwg = 0;
+
 template <int L, typename T>
 static std::vector<cx<T>> twiddles() {   // the per-pass table the device plan uploads
     using Cfg = typename CfgFor<L>::Cfg;
@@ -92,6 +95,17 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     p.mode = mode;
     const int gy = (mode == COL_PER_IMAGE) ? frames * V : frames;   // as rlsted.cpp col_t()
     if (mode != COL_PER_IMAGE && !WavePrivate<Cfg>::value) return -3;
+    p.images = gy;
+    if constexpr (WavePrivate<Cfg>::value) {
+        if (g_stream_nwg > 0 && mode == COL_PER_IMAGE) {
+            const int nwg = g_stream_nwg;
+            run_grid(nwg, 1, 64 * C, ((size_t)C * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
+                     [&](int tid, int bx, int, unsigned char* lds, EmuSync& s) {
+                         colstream_body<Cfg, C, T>(p, tid, bx, nwg, reinterpret_cast<cx<T>*>(lds), s);
+                     });
+            return 0;
+        }
+    }
     run_grid((kx + C - 1) / C, gy, Cfg::T * C, (size_t)C * LdsLen<L>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  if constexpr (WavePrivate<Cfg>::value)
@@ -112,6 +126,19 @@ static int row_m(const RowParams<T>& p, int gy) {
     using Cfg = typename CF::Cfg;
     constexpr int Q = sizeof(T) == 4 ? CF::Q32 : CF::Q64;
     const int pairs = (p.ny + 1) / 2;
+    if constexpr (WavePrivate<Cfg>::value && (MODE == ROW_RATIO || MODE == ROW_UPDATE)) {
+        if (g_stream_nwg > 0 && (MODE == ROW_RATIO || p.V == 1)) {
+            constexpr int QS = 2;   // two waves per workgroup: several items per wave at test sizes
+            const int nwg = g_stream_nwg;
+            RowParams<T> ps = p;
+            ps.frames = gy;
+            run_grid(nwg, 1, 64 * QS, ((size_t)QS * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
+                     [&](int tid, int bx, int, unsigned char* lds, EmuSync& s) {
+                         rowstream_body<Cfg, QS, MODE, T>(ps, tid, bx, nwg, reinterpret_cast<cx<T>*>(lds), s);
+                     });
+            return 0;
+        }
+    }
     run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsLen<L>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
@@ -152,6 +179,10 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
     }
 
 extern "C" {
+
+// nwg > 0: the streaming bodies (colstream_body / rowstream_body) with nwg persistent workgroups
+// stand in for the tiled ones wherever rlsted.cpp would launch them; 0: tiled bodies
+void emu_set_stream(int nwg) { g_stream_nwg = nwg; }
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {

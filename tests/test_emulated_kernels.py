@@ -32,6 +32,17 @@ def emu():
     return ctypes.CDLL(so)
 
 
+def _slack(a):
+    """Copy of `a` that is followed in memory by 16 KiB of slack: the streaming row bodies load
+    whole 64-lane segments, so lanes past the end of the last row read (and discard) bytes
+    behind the array -- the device plan allocates RL_STREAM_SLACK behind every buffer for this."""
+    a = np.ascontiguousarray(a)
+    raw = np.zeros(a.nbytes + 16384, dtype=np.uint8)
+    out = raw[:a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -99,7 +110,7 @@ class EmuPlan:
 
     def spec(self, n):
         # NaN-poisoned so that any read of a never-written element shows up
-        return np.full((n, self.ny, self.pitch), np.nan + 1j * np.nan, dtype=self.ct)
+        return _slack(np.full((n, self.ny, self.pitch), np.nan + 1j * np.nan, dtype=self.ct))
 
     def H(self, x):
         B = x.shape[0]
@@ -122,9 +133,9 @@ class EmuPlan:
 
     def rl(self, meas, K, fuse=False):
         B = meas.shape[0]
-        meas = np.ascontiguousarray(meas.reshape(B * self.V, self.ny, self.nx), dtype=self.rt)
-        norm = self.normalization()
-        est = np.ones((B, self.ny, self.nx), dtype=self.rt)
+        meas = _slack(np.ascontiguousarray(meas.reshape(B * self.V, self.ny, self.nx), dtype=self.rt))
+        norm = _slack(self.normalization())
+        est = _slack(np.ones((B, self.ny, self.nx), dtype=self.rt))
         sa, sb = self.spec(B), self.spec(B * self.V)
         self.row(ROW_FWD, B, spec_out=sa, src=est)
         for _ in range(K):
@@ -255,3 +266,54 @@ def test_golden_rl_through_emulated_kernels(emu, golden):
     assert max_rel(norm, g['rings_point_1p5x/norm'][0]) < 1e-13
     ref = g['rings_point_1p5x/estimate_2'][0]
     assert (np.abs(est[0] - ref) / np.abs(ref)).max() < 1e-9
+
+
+@pytest.mark.parametrize('nwg', [1, 3, 8])
+def test_streaming_bodies_match_tiled_bodies(emu, nwg):
+    """The persistent, prefetching RL kernels (colstream_body / rowstream_body; wave-private
+    lengths, one view) against the tiled ones and the oracle: several work items per
+    workgroup, odd ny (a row pair with one row), partial last column tile, in-place spectra."""
+    emu.emu_set_stream.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(11)
+    ny, nx = 45, 70
+    psfs = [rng.random((1, 9, 7))]
+    obj = rng.random((3, ny, nx)) * 40
+    d = orc.Deconvolver(psfs)
+    d.create_data_from_object(obj, random_seed=0)
+    for _ in range(3):
+        d.iterate()
+    meas = np.array(d.noisy_measurement)[0][:, None]                                    # (B=3, V=1, ny, nx)
+    pl = EmuPlan(emu, psfs, ny, nx, 192, 192)
+    try:
+        emu.emu_set_stream(0)
+        tiled, _ = pl.rl(meas, 3)
+        emu.emu_set_stream(nwg)
+        streamed, _ = pl.rl(meas, 3)
+    finally:
+        emu.emu_set_stream(0)
+    assert np.array_equal(streamed, tiled)          # same arithmetic, only the schedule differs
+    assert max_rel(streamed, d.estimate) < 1e-11
+
+
+def test_streaming_bodies_l576_f32(emu):
+    """The headline geometry (576 = 9*8*8 with cross-lane tails) through the streaming bodies, f32."""
+    emu.emu_set_stream.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(12)
+    ny, nx = 20, 530
+    psfs = [rng.random((1, 5, 41))]
+    obj = rng.random((2, ny, nx)) * 40
+    d = orc.Deconvolver(psfs)
+    d.create_data_from_object(obj, random_seed=0)
+    for _ in range(2):
+        d.iterate()
+    meas = np.array(d.noisy_measurement)[0][:, None]                                    # (B=2, V=1, ny, nx)
+    pl = EmuPlan(emu, psfs, ny, nx, 64, 576, np.float32)
+    try:
+        emu.emu_set_stream(0)
+        tiled, _ = pl.rl(meas, 2)
+        emu.emu_set_stream(3)
+        streamed, _ = pl.rl(meas, 2)
+    finally:
+        emu.emu_set_stream(0)
+    assert np.array_equal(streamed, tiled)
+    assert max_rel(streamed, d.estimate) < 2e-5

@@ -205,6 +205,44 @@ def test_many_frames_persistent_column_kernel_orders(lib, golden):
             assert np.array_equal(one.estimate()[0], est[f])
 
 
+@pytest.mark.parametrize('dtype,tol', [('f32', F32_TOL), ('f64', F64_TOL)])
+def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatch):
+    """The RL loop has switchable kernel flavours (read from the environment when a plan is
+    made): streaming = persistent prefetching column / RATIO / UPDATE kernels (RLSTED_STREAM bit
+    mask), in place = single-view iterations entirely in spec_a (RLSTED_INPLACE).  Every
+    combination must give the default's result (same arithmetic, schedule and buffers differ;
+    only the compiler's fma contraction may differ between two instantiations) and the oracle's.
+    B = 19 frames of 512x512: several work items per persistent workgroup, an item count that is
+    not a multiple of 8 (fallback work order), odd frame count."""
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    rng = np.random.default_rng(5)
+    B, K = 19, 6
+    objs = np.concatenate([astronaut512, rng.random((B - 1, 512, 512)) * 200])
+    d = orc.Deconvolver(psf)
+    d.create_data_from_object(objs[:2], total_brightness=2 * 8e11, random_seed=3)
+    for _ in range(K):
+        d.iterate()
+    results = {}
+    noisy = None
+    for stream, inplace in (('0', '1'), ('7', '1'), ('7', '0'), ('0', '0'), ('5', '1'), ('2', '0')):
+        monkeypatch.setenv('RLSTED_STREAM', stream)
+        monkeypatch.setenv('RLSTED_INPLACE', inplace)
+        plan = lib.DeconvPlan(psf, B, 512, 512, dtype=dtype)
+        plan.set_object(objs, 8e11)
+        if noisy is None:
+            plan.simulate(seed=9)
+            noisy = plan.measurement()
+            noisy[:2, 0] = np.array(d.noisy_measurement)[0]       # frames 0, 1: the oracle's draw
+        plan.set_measurement(noisy)
+        plan.iterate(K)
+        results[(stream, inplace)] = plan.estimate()
+        del plan
+    ref = results[('0', '1')]
+    assert max_rel(ref[:2], d.estimate) < tol
+    for key, est in results.items():
+        assert max_rel(est, ref) < (2e-6 if dtype == 'f32' else 1e-13), key
+
+
 # ------------------------------------- BASELINE configs 3 and 5: large images
 def test_2048_line_rescan_batch_vs_oracle(lib, golden):
     """Config 3 shape: synthetic 2048x2048 random object, line-rescan (4 views), a

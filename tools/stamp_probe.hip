@@ -57,6 +57,39 @@ __global__ void __launch_bounds__(64 * Q) k_row(const RowParams<float> p, unsign
     rowpass_body<Cfg, Q, MODE, true, float>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<float>*>(smem), s);
 }
 
+#ifndef PROBE_COL_MINW
+#define PROBE_COL_MINW 1
+#endif
+#ifndef PROBE_ROW_MINW
+#define PROBE_ROW_MINW 1
+#endif
+#ifndef PROBE_QS
+#define PROBE_QS 8
+#endif
+struct PlainSync : DevSync {
+    unsigned long long* buf;
+};
+template <class S, int C>
+__global__ void __launch_bounds__(64 * C, PROBE_COL_MINW) k_cols(const ColParams<float> p, unsigned long long* buf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    S s; s.buf = buf;
+    colstream_body<Cfg, C, float>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<float>*>(smem), s);
+}
+template <class S, int Q, int MODE>
+__global__ void __launch_bounds__(64 * Q, PROBE_ROW_MINW) k_rows(const RowParams<float> p, unsigned long long* buf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    S s; s.buf = buf;
+    rowstream_body<Cfg, Q, MODE, float>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<float>*>(smem), s);
+}
+template <typename F>
+static int resident(F* fn, int threads, size_t lds) {
+    int per_cu = 0;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds));
+    printf("    (%d workgroups of %d threads per CU, %zu B LDS)\n", per_cu, threads, lds);
+    return per_cu * 256;
+}
+
 static void report(const char* name, const std::vector<unsigned long long>& h, size_t waves, int ns, float ms) {
     std::vector<double> d(ns, 0.0);
     double life = 0;
@@ -89,12 +122,12 @@ int main(int argc, char** argv) {
     unsigned long long* stamps;
     CHECK(hipMalloc(&tw, twf.size() * 4));
     CHECK(hipMemcpy(tw, twf.data(), twf.size() * 4, hipMemcpyHostToDevice));
-    CHECK(hipMalloc(&spec_a, B * simg * 8));
-    CHECK(hipMalloc(&spec_b, B * simg * 8));
+    CHECK(hipMalloc(&spec_a, B * simg * 8 + RL_STREAM_SLACK));
+    CHECK(hipMalloc(&spec_b, B * simg * 8 + RL_STREAM_SLACK));
     CHECK(hipMalloc(&psf_hat, (size_t)kx * L * 8));
-    CHECK(hipMalloc(&meas, B * rimg * 4));
-    CHECK(hipMalloc(&est, B * rimg * 4));
-    CHECK(hipMalloc(&norm, rimg * 4));
+    CHECK(hipMalloc(&meas, B * rimg * 4 + RL_STREAM_SLACK));
+    CHECK(hipMalloc(&est, B * rimg * 4 + RL_STREAM_SLACK));
+    CHECK(hipMalloc(&norm, rimg * 4 + RL_STREAM_SLACK));
     {
         std::vector<float> r(B * simg * 2);
         for (auto& x : r) x = 0.5f + (float)rand() / RAND_MAX;
@@ -141,5 +174,36 @@ int main(int argc, char** argv) {
     timeit([&] { k_row<StampSync, Q, ROW_RATIO><<<dim3(gxr, B), 64 * Q, ldr>>>(rp, stamps); }, "row RATIO (draining)", row_waves, 6);
     timeit([&] { k_row<StampSyncLazy, Q, ROW_UPDATE><<<dim3(gxr, B), 64 * Q, ldr>>>(rp, stamps); }, "row UPDATE (lazy)", row_waves, 6);
     timeit([&] { k_row<StampSync, Q, ROW_UPDATE><<<dim3(gxr, B), 64 * Q, ldr>>>(rp, stamps); }, "row UPDATE (draining)", row_waves, 6);
+    // streaming kernels: the stamps of each wave's LAST item survive
+    cp.images = B; rp.frames = B;
+    constexpr int QS = PROBE_QS;
+    const size_t ldcs = ((size_t)C * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * 8, ldrs = ((size_t)QS * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * 8;
+    auto plain = [&](auto launch, const char* name) {
+        float ms = 0, best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+            CHECK(hipEventRecord(e0));
+            launch();
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipGetLastError());
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        printf("%-28s %.3f ms (no stamps, best of 4)\n", name, best);
+    };
+    {
+        const int n = resident(k_cols<PlainSync, C>, 64 * C, ldcs);
+        plain([&] { k_cols<PlainSync, C><<<n, 64 * C, ldcs>>>(cp, stamps); }, "colstream");
+        const int n2 = resident(k_rows<PlainSync, QS, ROW_RATIO>, 64 * QS, ldrs);
+        plain([&] { k_rows<PlainSync, QS, ROW_RATIO><<<n2, 64 * QS, ldrs>>>(rp, stamps); }, "rowstream RATIO");
+        const int n3 = resident(k_rows<PlainSync, QS, ROW_UPDATE>, 64 * QS, ldrs);
+        plain([&] { k_rows<PlainSync, QS, ROW_UPDATE><<<n3, 64 * QS, ldrs>>>(rp, stamps); }, "rowstream UPDATE");
+    }
+    const int nc = resident(k_cols<StampSyncLazy, C>, 64 * C, ldcs);
+    timeit([&] { k_cols<StampSyncLazy, C><<<nc, 64 * C, ldcs>>>(cp, stamps); }, "colstream (lazy)", (size_t)nc * C, 8);
+    const int nr = resident(k_rows<StampSyncLazy, QS, ROW_RATIO>, 64 * QS, ldrs);
+    timeit([&] { k_rows<StampSyncLazy, QS, ROW_RATIO><<<nr, 64 * QS, ldrs>>>(rp, stamps); }, "rowstream RATIO (lazy)", (size_t)nr * QS, 6);
+    const int nu = resident(k_rows<StampSyncLazy, QS, ROW_UPDATE>, 64 * QS, ldrs);
+    timeit([&] { k_rows<StampSyncLazy, QS, ROW_UPDATE><<<nu, 64 * QS, ldrs>>>(rp, stamps); }, "rowstream UPDATE (lazy)", (size_t)nu * QS, 6);
     return 0;
 }
