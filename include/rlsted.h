@@ -147,6 +147,19 @@ int rl_psf_report(rl_ctx* ctx, int psf_type, double excitation_brightness, doubl
  * clipped to [0, 1.1 * max(in)].  Host in / out, float64.                       */
 int rl_rotate_psf(rl_ctx* ctx, const double* in, double* out, int ny, int nx, double degrees);
 
+/* ---- reconstruction quality (line_sted_tools.py:539-547, line_sted_figure_2.py:353-390) ----
+ * out[i] = f(|fftshift(fft2(x[i]))| * scale) for n_img real images [n_img][ny][nx] of any
+ * size, f(m) = log(1 + m) when log1p != 0, else m.  record_iteration's FT-error history is
+ * (x = estimate_k - truth, scale 1, log1p 1); fourier_error of the figure-2 harness
+ * (:353-355) is (x = estimate - truth, scale 1/(ny*nx), log1p 0).                      */
+int rl_fft2_magnitude(rl_ctx* ctx, const double* x, int n_img, int ny, int nx, double scale, int log1p,
+                      double* out);
+
+/* scipy.ndimage.map_coordinates(image, [ys, xs]) with its defaults (order 3, mode 'constant',
+ * cval 0, prefilter) for a [ny][nx] image at n points (:381-384): out[n].               */
+int rl_spline_sample(rl_ctx* ctx, const double* image, int ny, int nx, const double* ys, const double* xs, int n,
+                     double* out);
+
 /* Per-kernel device time: launches each kernel of the RL iteration `reps`
  * times back to back between two hipEvents on the plan's stream and returns
  * the average milliseconds per launch in avg_ms[6] = { column pass (H),

@@ -272,4 +272,10 @@ hipError_t psf_spline_rotate(const double* in, double* work, double* out, double
     return hipGetLastError();
 }
 
+hipError_t psf_spline_prefilter(double* a, int ny, int nx, hipStream_t s) {
+    k_spline_prefilter<<<nblk(nx), 256, 0, s>>>(a, ny, nx, 0);
+    k_spline_prefilter<<<nblk(ny), 256, 0, s>>>(a, ny, nx, 1);
+    return hipGetLastError();
+}
+
 }  // namespace rl

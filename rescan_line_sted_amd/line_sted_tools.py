@@ -184,12 +184,8 @@ class Deconvolver:
             eh = np.squeeze(np.concatenate(self.estimate_history, axis=0))
             np_tif.array_to_tif(eh, self.output_prefix + 'estimate_history.tif')
 
-            def f(x):
-                if len(x.shape) == 2:
-                    x = x.reshape(1, x.shape[0], x.shape[1])
-                return np.log(1 + np.abs(np.fft.fftshift(
-                    np.fft.fftn(x, axes=(1, 2)), axes=(1, 2))))
-            np_tif.array_to_tif(f(eh - self.true_object),
+            from .quality import ft_error_history       # ref:539-547, float64 on the device
+            np_tif.array_to_tif(ft_error_history(eh, self.true_object),
                                 self.output_prefix + 'estimate_FT_error_history.tif')
         return None
 

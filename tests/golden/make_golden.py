@@ -235,10 +235,49 @@ def g9_progress():
     save('g9_progress.npz', **out)
 
 
+def g10_quality():
+    """(a) record_iteration()'s history files as the reference writes them (float32 TIFF stacks,
+    line_sted_tools.py:533-547), read back with the reference's np_tif; (b) the Fourier error
+    map and its line profiles -- line_sted_figure_2.py:353-390 lives inside a figure function
+    that cannot be called piecewise, so its numpy/scipy calls are issued here on the same data."""
+    from scipy.ndimage import map_coordinates, gaussian_filter
+    objs = _objects()
+    psfs = np.load(os.path.join(HERE, 'g8_fig2_psfs.npz'))
+    obj = objs['rings'].astype(np.float64)
+    prefix = '/tmp/_golden_tmp/q_'
+    d = st.Deconvolver(list(psfs['1p5x_lr/point_sted_psf']), output_prefix=prefix, verbose=False)
+    d.create_data_from_object(obj, total_brightness=5e10, random_seed=0)
+    for _, flag in st.logarithmic_progress(range(9), verbose=False):   # saves after iterations 2,3,5,9
+        d.iterate()
+        if flag:
+            d.record_iteration()
+    out = {'saved_iterations': np.array(d.saved_iterations),
+           'noisy': np.array(d.noisy_measurement),
+           'true_object': d.true_object,
+           'estimate': d.estimate.copy(),
+           'estimate_history_tif': np_tif.tif_to_array(prefix + 'estimate_history.tif'),
+           'ft_error_history_tif': np_tif.tif_to_array(prefix + 'estimate_FT_error_history.tif')}
+    est, true_object = d.estimate[0], d.true_object[0]
+    fe = np.abs(np.fft.fftshift(np.fft.fftn(est - true_object))) / np.prod(true_object.shape)   # :353-355
+    out['fourier_error'] = fe
+    n_x, n_y = true_object.shape                                                                 # :363
+    samps, rad = 1000, 0.3
+    for tag, ang_deg in (('best', 0.0), ('worst', 90 / 4)):                                      # :364,370
+        ang = ang_deg * 2 * np.pi / 360
+        x0, x1 = (0.5 + rad * np.array((-np.cos(ang), np.cos(ang)))) * n_x
+        y0, y1 = (0.5 + rad * np.array((-np.sin(ang), np.sin(ang)))) * n_y
+        xy = np.vstack((np.linspace(x0, x1, samps), np.linspace(y0, y1, samps)))                 # :379
+        z = map_coordinates(np.transpose(fe), xy)                                                # :383
+        out['profile_raw_' + tag] = z
+        out['profile_' + tag] = gaussian_filter(z, sigma=samps / 80)                             # :387
+        out['angle_' + tag] = np.array(ang_deg)
+    save('g10_quality.npz', **out)
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g4', 'g9', 'g8', 'g5', 'g3']
     os.makedirs('/tmp/_golden_tmp', exist_ok=True)
     for t in todo:
         {'g1': g1_psf_report, 'g2': g2_get_width, 'g3': g3_tune_psf,
          'g4': g4_conv, 'g5': g5_rl, 'g8': g8_fig2_psfs,
-         'g9': g9_progress}[t]()
+         'g9': g9_progress, 'g10': g10_quality}[t]()

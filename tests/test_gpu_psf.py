@@ -180,3 +180,63 @@ def test_reduced_figure_2_sweep(golden):
         plan.simulate(seed=s)
         plan.iterate(4)
         assert np.array_equal(plan.estimate()[frames.index(tasks[i])], est[i])
+
+
+# ------------------------------------------------ reconstruction quality
+def test_quality_metrics_match_reference(golden):
+    """Device Fourier-error metrics against the reference's own numbers (g10)."""
+    from rescan_line_sted_amd import quality
+    g = golden('g10_quality')
+    est, truth = g['estimate'][0], g['true_object'][0]
+    fe = quality.fourier_error(est, truth)
+    assert max_rel(fe, g['fourier_error']) < 1e-12
+    for tag in ('best', 'worst'):
+        ang = float(g['angle_' + tag])
+        raw = quality.error_vs_spatial_frequency(est, truth, angle_degrees=ang, smooth=False)
+        assert max_rel(raw, g['profile_raw_' + tag]) < 1e-11
+        assert max_rel(quality.error_vs_spatial_frequency(est, truth, angle_degrees=ang), g['profile_' + tag]) < 1e-11
+    hist = quality.ft_error_history(g['estimate_history_tif'].astype(np.float64), truth)
+    assert max_rel(hist, g['ft_error_history_tif']) < 2e-5          # inputs and outputs are float32 on disk
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (2, 3), (7, 1), (33, 64), (160, 160), (100, 37)])
+def test_fft2_magnitude_any_shape_vs_numpy(shape):
+    from rescan_line_sted_amd import quality
+    rng = np.random.default_rng(sum(shape))
+    x, t = rng.random((3,) + shape), rng.random(shape)
+    ref = np.abs(np.fft.fftshift(np.fft.fftn(x - t, axes=(1, 2)), axes=(1, 2)))
+    assert max_rel(quality.fourier_error(x, t), ref / (shape[0] * shape[1])) < 1e-12
+    assert max_rel(quality.ft_error_history(x, t), np.log(1 + ref)) < 1e-12
+    assert max_rel(quality.fourier_error(x[0], t), orc.fourier_error(x[0], t)) < 1e-12
+
+
+def test_map_coordinates_vs_oracle():
+    from rescan_line_sted_amd import quality
+    rng = np.random.default_rng(9)
+    a = rng.random((40, 53))
+    ys, xs = rng.uniform(-3, 43, 700), rng.uniform(-3, 56, 700)
+    ys[:4], xs[:4] = [0, 39, 39, 0], [0, 52, 0, 52]
+    got = quality.map_coordinates(a, [ys, xs])
+    assert np.abs(got - orc.map_coordinates_cubic(a, ys, xs)).max() < 1e-13
+    assert quality.map_coordinates(a, np.zeros((2, 0))).shape == (0,)
+
+
+def test_record_iteration_writes_reference_history(st, golden, tmp_path):
+    """Deconvolver.record_iteration through the device FT-error path reproduces the files the
+    reference wrote for the same run (same measurement, same save schedule)."""
+    from rescan_line_sted_amd import np_tif
+    g = golden('g10_quality')
+    psf = list(golden('g8_fig2_psfs')['1p5x_lr/point_sted_psf'])
+    d = st.Deconvolver(psf, output_prefix=str(tmp_path) + '/q_', verbose=False)
+    d.create_data_from_object(golden('objects')['rings'].astype(np.float64), total_brightness=5e10, random_seed=0)
+    d.noisy_measurement = [m.copy() for m in g['noisy']]
+    for _, flag in st.logarithmic_progress(range(9), verbose=False):
+        d.iterate()
+        if flag:
+            d.record_iteration()
+    assert d.saved_iterations == list(g['saved_iterations'])
+    eh = np_tif.tif_to_array(str(tmp_path) + '/q_estimate_history.tif')
+    fh = np_tif.tif_to_array(str(tmp_path) + '/q_estimate_FT_error_history.tif')
+    assert eh.dtype == np.float32 and fh.dtype == np.float32
+    assert max_rel(eh, g['estimate_history_tif']) < 1e-6
+    assert max_rel(fh, g['ft_error_history_tif']) < 1e-6

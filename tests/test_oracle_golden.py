@@ -160,3 +160,29 @@ def test_g8_fig2_psf_sets(golden, name):
     assert len(c['line_sted_psfs']) == int(nori)
     for a, b in zip(c['line_sted_psfs'], g8[name + '/line_sted_psfs']):
         assert max_rel(a, b) < 1e-6                # tune_psf agrees to ~1e-8; see test_g3_tune_psf
+
+
+def test_g10_quality_metrics(golden):
+    """The Fourier-error metrics against what the reference wrote (record_iteration's float32
+    TIFF history, line_sted_tools.py:533-547) and against the figure-2 harness' numpy/scipy
+    calls (line_sted_figure_2.py:353-390) on the reference's own RL run."""
+    g = golden('g10_quality')
+    est, truth = g['estimate'][0], g['true_object'][0]
+    assert list(g['saved_iterations']) == [2, 3, 5, 9]      # flags at i = 1, 2, 4, 8 (= last)
+    fe = orc.fourier_error(est, truth)
+    assert max_rel(fe, g['fourier_error']) < 1e-13
+    for tag in ('best', 'worst'):
+        z = orc.error_vs_spatial_frequency(est, truth, angle_degrees=float(g['angle_' + tag]))
+        assert max_rel(z, g['profile_' + tag]) < 1e-12
+    # the history on disk is float32 (np_tif coerces, np_tif.py:145-151) of float64 estimates
+    hist = orc.ft_error_history(g['estimate_history_tif'].astype(np.float64), truth)
+    assert max_rel(hist, g['ft_error_history_tif']) < 2e-5   # inputs known to float32 only
+
+
+def test_map_coordinates_restates_scipy():
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(8)
+    a = rng.random((23, 31))
+    ys, xs = rng.uniform(-2, 25, 300), rng.uniform(-2, 33, 300)
+    ys[:4], xs[:4] = [0, 22, 22, 0], [0, 30, 0, 30]                 # the corners are inside
+    assert np.abs(orc.map_coordinates_cubic(a, ys, xs) - map_coordinates(a, [ys, xs])).max() < 1e-13
