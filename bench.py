@@ -153,6 +153,7 @@ def main():
 
     # dominant-kernel roofline, measured live with HIP events on the plan's stream
     kt = plan.time_kernels(args.kernel_reps)
+    FL = kt.pop('frames_per_rl_launch')         # frames per launch of the RL kernels (batch slices)
     n_pix, V = NY * NX, len(psf)
     info = plan.info()
     es = 4 if args.dtype == 'f32' else 8
@@ -167,14 +168,14 @@ def main():
     per_cycle_ms = {k: kt[k] * launches[k][0] for k in launches}
     dom = max(per_cycle_ms, key=per_cycle_ms.get)
     iter_ms = kt['colconv_H'] + kt['rowpass_RATIO'] + kt['colconv_Ht'] + kt['rowpass_UPDATE']
-    alg_iter = 4 * n_pix * (3 * V + 4) * B      # algorithmic bytes of one RL iteration over the batch
+    alg_iter = 4 * n_pix * (3 * V + 4) * FL     # algorithmic bytes of one RL iteration over one slice
     # the dominant kernel's share of the iteration's algorithmic bytes: pass 1
     # (H + ratio) moves 4N(2V+1), pass 2 (H_t + update) 4N(V+3); each pass is one
     # column launch + one row launch, the bytes are attributed to the pass's row
     # kernel (which touches the images) and the column kernel is charged its
     # pass's bytes as well, i.e. achieved = pass bytes / (pass's two launches).
-    pass1 = 4 * n_pix * (2 * V + 1) * B
-    pass2 = 4 * n_pix * (V + 3) * B
+    pass1 = 4 * n_pix * (2 * V + 1) * FL
+    pass2 = 4 * n_pix * (V + 3) * FL
     if dom in ('colconv_H', 'rowpass_RATIO'):
         pass_bytes, pass_ms = pass1, kt['colconv_H'] + kt['rowpass_RATIO']
     else:
@@ -186,7 +187,7 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
-        if (pmc.get('batch') == B and pmc.get('dtype') == args.dtype and pmc.get('n_psf') == V
+        if (pmc.get('frames_per_launch') == FL and pmc.get('dtype') == args.dtype and pmc.get('n_psf') == V
                 and pmc.get('shape') == [NY, NX] and dom in pmc):
             traffic = pmc[dom]['hbm_bytes_per_launch']
     except (OSError, ValueError):
@@ -196,7 +197,8 @@ def main():
         'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
         'algorithmic_bytes_per_launch_pair': pass_bytes,
         'kernel_avg_ms': kt,
-        'kernel_moved_GBps': {k: launches[k][1] * B / (kt[k] * 1e-3) / 1e9 for k in launches},
+        'frames_per_launch': FL,
+        'kernel_moved_GBps': {k: launches[k][1] * FL / (kt[k] * 1e-3) / 1e9 for k in launches},
         'rl_iteration': {'ms': iter_ms, 'algorithmic_GBps': alg_iter / (iter_ms * 1e-3) / 1e9,
                          'frac': alg_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         'whole_path': {'algorithmic_bytes_per_frame': algorithmic_bytes_per_frame(n_pix, V, K_ITERS),

@@ -162,8 +162,11 @@ int rl_spline_sample(rl_ctx* ctx, const double* image, int ny, int nx, const dou
 
 /* Per-kernel device time: launches each kernel of the RL iteration `reps`
  * times back to back between two hipEvents on the plan's stream and returns
- * the average milliseconds per launch in avg_ms[6] = { column pass (H),
- * row pass RATIO, column pass (H_t), row pass UPDATE, row pass FWD, Poisson }.
+ * the average milliseconds per launch in avg_ms[0..5] = { column pass (H),
+ * row pass RATIO, column pass (H_t), row pass UPDATE, row pass FWD, Poisson };
+ * avg_ms[6] = frames covered by one launch of the four RL kernels (the RL
+ * loop works through the batch in equal slices sized for the Infinity Cache;
+ * FWD and Poisson run over the whole batch).  avg_ms must hold 7 doubles.
  * Destroys the current estimate (the next iterate restarts from 1).          */
 int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms);
 

@@ -218,7 +218,9 @@ class DeconvPlan:
     KERNEL_NAMES = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'poisson')
 
     def time_kernels(self, reps=20):
-        out = np.zeros(6, dtype=np.float64)
+        out = np.zeros(7, dtype=np.float64)
         check(lib.rl_deconv_time_kernels(self.handle, int(reps), ptr(out)))
-        return dict(zip(self.KERNEL_NAMES, out.tolist()))
+        kt = dict(zip(self.KERNEL_NAMES, out[:6].tolist()))
+        kt['frames_per_rl_launch'] = int(out[6])      # the RL loop works through the batch in slices
+        return kt
 

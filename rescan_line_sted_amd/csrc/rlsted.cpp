@@ -630,20 +630,29 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
     if (!h->est_ready) RL_TRY(h->start_estimate());
     // one untimed iteration so that every buffer holds realistic data
     RL_TRY(h->iterate_once());
+    // the RL kernels are timed on the launch shape the RL loop uses: one slice of the batch
+    const int nf = h->chunk_frames();
+    avg_ms[6] = (double)nf;
     for (int which = 0; which < 6; ++which) {
         HIP_TRY(hipEventRecord(h->ev0, s));
         for (int r = 0; r < reps; ++r) {
+            const bool one_buffer = h->V == 1 && h->inplace;   // as iterate_chunk(): everything in spec_a
             switch (which) {
-                case 0: RL_TRY(h->col(h->spec_a, h->spec_b, h->B, true)); break;
-                case 1: RL_TRY(h->row(ROW_RATIO, (unsigned)(h->B * h->V), h->spec_b, h->spec_b, h->meas, nullptr, nullptr)); break;
-                case 2:   // as iterate_chunk(): fused (Fourier-domain view sum) or per view
-                    if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->spec_b, h->spec_a, h->B, rl_deconv::COL_HT_FUSED));
-                    else RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false));
+                case 0: RL_TRY(h->col(h->spec_a, one_buffer ? h->spec_a : h->spec_b, nf, true)); break;
+                case 1:
+                    if (one_buffer) RL_TRY(h->row(ROW_RATIO, (unsigned)nf, h->spec_a, h->spec_a, h->meas, nullptr, nullptr));
+                    else RL_TRY(h->row(ROW_RATIO, (unsigned)(nf * h->V), h->spec_b, h->spec_b, h->meas, nullptr, nullptr));
+                    break;
+                case 2:   // as iterate_chunk(): in place, fused (Fourier-domain view sum) or per view
+                    if (one_buffer) RL_TRY(h->col(h->spec_a, h->spec_a, nf, false));
+                    else if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->spec_b, h->spec_a, nf, rl_deconv::COL_HT_FUSED));
+                    else RL_TRY(h->col(h->spec_b, h->spec_b, nf, false));
                     break;
                 case 3:
-                    if (h->fuse_views && h->V > 1 && h->wave_private_y())
-                        RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_a, h->spec_a, nullptr, h->est, h->norm, nullptr, 1));
-                    else RL_TRY(h->row(ROW_UPDATE, (unsigned)h->B, h->spec_b, h->spec_a, nullptr, h->est, h->norm));
+                    if (one_buffer) RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_a, h->spec_a, nullptr, h->est, h->norm));
+                    else if (h->fuse_views && h->V > 1 && h->wave_private_y())
+                        RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_a, h->spec_a, nullptr, h->est, h->norm, nullptr, 1));
+                    else RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_b, h->spec_a, nullptr, h->est, h->norm));
                     break;
                 case 4: RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->obj, nullptr, nullptr)); break;
                 case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 1, RL_RNG_PHILOX, h->scratch, s)); break;

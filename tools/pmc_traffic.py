@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes over bench.py into profiles/rNN/pmc_traffic.json.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- \
+        python bench.py --steps 1 --warmup 0 --no-cpu-baseline --kernel-reps 2
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- (same)
+    python tools/pmc_traffic.py <fetch counter csv> <write counter csv> <out json> [batch]
+
+Only the most frequent launch shape of each kernel is kept: for the four RL kernels that is
+the slice of the batch the RL loop launches them on (bench.py: roofline.frames_per_launch, pass it
+as the 4th argument), the shape bench.py times for `roofline`.  FETCH_SIZE / WRITE_SIZE are reported in KB (1024 B); FETCH_SIZE is
+doubled (MI355X_MICROARCH.md, HBM/rocprofv3 section: gfx950 reports half the bytes of coalesced
+streaming reads; re-calibrated here on rowpass_FWD, which must read batch x ny x nx x 4 bytes).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+NAMES = (  # (regex on the kernel name, key in the json); first match wins
+    (r'k_rowpass<\d+, \d+, 0,', 'rowpass_FWD'), (r'k_rowpass<\d+, \d+, 1,', 'rowpass_INV'),
+    (r'k_rowpass<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpass<\d+, \d+, 3,', 'rowpass_UPDATE'),
+    (r'k_rowpass<\d+, \d+, 4,', 'rowpass_ADJ'), (r'k_rowstream<\d+, \d+, 2,', 'rowstream_RATIO'),
+    (r'k_rowstream<\d+, \d+, 3,', 'rowstream_UPDATE'), (r'k_colstream<', 'colstream'),
+    (r'k_colconv<', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'))
+
+
+def per_kernel(path, counter):
+    rows = defaultdict(list)   # key -> [(grid, value)]
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] != counter:
+                continue
+            for rx, key in NAMES:
+                if re.search(rx, r['Kernel_Name']):
+                    rows[key].append((int(r['Grid_Size']), float(r['Counter_Value'])))
+                    break
+    out = {}
+    for key, v in rows.items():
+        grids = [g for g, _ in v]
+        common = max(set(grids), key=grids.count)     # the launch shape that dominates the run
+        sel = [x for g, x in v if g == common]
+        out[key] = sum(sel) / len(sel)
+    return out
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+    fl = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+    batch = 256
+    res = {'_how': __doc__.strip().split('\n\n')[0] + ' (tools/pmc_traffic.py; FETCH_SIZE doubled, KB = 1024 B)',
+           'batch': batch, 'frames_per_launch': fl, 'dtype': 'f32', 'shape': [512, 512], 'n_psf': 1}
+    for key in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(key, 0.0), write.get(key, 0.0)
+        res[key] = {'hbm_bytes_per_launch': 2 * f * 1024 + w * 1024, 'fetch_kb_reported': f, 'write_kb_reported': w}
+    if 'colconv' in res:   # the H and H_t column passes are the same kernel
+        res['colconv_H'] = res['colconv_Ht'] = res['colconv']
+    if 'rowpass_FWD' in res:
+        res['_calibration'] = {'rowpass_FWD_must_read_bytes': batch * 512 * 512 * 4,
+                               'rowpass_FWD_fetch_reported_bytes': res['rowpass_FWD']['fetch_kb_reported'] * 1024}
+    json.dump(res, open(sys.argv[3], 'w'), indent=1)
+    print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in res.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v}))
+
+
+if __name__ == '__main__':
+    main()
