@@ -82,6 +82,16 @@ struct rl_deconv {
     // 2 ROW_RATIO, 4 ROW_UPDATE.  Off by default: measured equal to the tiled kernels inside the
     // chunked RL loop; RLSTED_STREAM=7 turns them on.
     int streaming = 0;
+    // Slices of the batch are independent: they are iterated on `lanes` HIP streams at once so that
+    // the tail of one slice's kernel (the last, partly filled round of workgroups) overlaps another
+    // slice's kernels.  RLSTED_LANES=1: one slice after the other on the context's stream.
+    static constexpr int kMaxLanes = 4;
+    int lanes = 2;
+    hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr;
+    hipStream_t active = nullptr;                     // stream the kernel launch helpers use
+    hipStream_t cur() const { return active ? active : ctx->stream; }
     bool inplace = true;     // single-view RL iterations entirely in spec_a (RLSTED_INPLACE=0: spec_a -> spec_b -> spec_a)
     bool est_ready = false;    // est holds a valid estimate
     bool spec_valid = false;   // spec_a holds rowFFT(est)
@@ -116,11 +126,11 @@ struct rl_deconv {
         const unsigned gx = (unsigned)((kx + C - 1) / C);
         p.images = (int)gy;
         if ((streaming & 1) && p.mode == COL_PER_IMAGE && ty->launch_col_stream)
-            HIP_TRY(ty->launch_col_stream(dtype, &p, ctx->stream));
+            HIP_TRY(ty->launch_col_stream(dtype, &p, cur()));
         else
-            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, ctx->stream));
+            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, cur()));
         if (rl::debug_sync()) {
-            hipError_t e = hipStreamSynchronize(ctx->stream);
+            hipError_t e = hipStreamSynchronize(cur());
             if (e != hipSuccess)
                 return fail(RL_ERR_HIP, "column kernel L=" + std::to_string(ly) + " grid " + std::to_string(gx) + "x" +
                                             std::to_string(gy) + ": " + hipGetErrorString(e));
@@ -147,11 +157,11 @@ struct rl_deconv {
         const unsigned pairs = (unsigned)((ny + 1) / 2);
         p.frames = (int)gy;
         if (tx->launch_row_stream && (((streaming & 2) && mode == ROW_RATIO) || ((streaming & 4) && mode == ROW_UPDATE && views == 1)))
-            HIP_TRY(tx->launch_row_stream(dtype, mode, &p, ctx->stream));
+            HIP_TRY(tx->launch_row_stream(dtype, mode, &p, cur()));
         else
-            HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, ctx->stream));
+            HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, cur()));
         if (rl::debug_sync()) {
-            hipError_t e = hipStreamSynchronize(ctx->stream);
+            hipError_t e = hipStreamSynchronize(cur());
             if (e != hipSuccess)
                 return fail(RL_ERR_HIP, "row kernel mode " + std::to_string(mode) + " L=" + std::to_string(lx) + " grid " +
                                             std::to_string((pairs + Q - 1) / Q) + "x" + std::to_string(gy) + ": " +
@@ -227,7 +237,8 @@ struct rl_deconv {
     // so the inter-kernel traffic is served on die instead of from HBM.
     char* off(void* base, size_t elems) const { return (char*)base + elems * esize(dtype); }
     int chunk_frames() const {
-        const double budget_mb = getenv("RLSTED_CHUNK_MB") ? atof(getenv("RLSTED_CHUNK_MB")) : 288.0;
+        // per slice; `lanes` slices are in flight at once, together about the 256 MiB Infinity Cache
+        const double budget_mb = getenv("RLSTED_CHUNK_MB") ? atof(getenv("RLSTED_CHUNK_MB")) : (lanes > 1 ? 108.0 : 288.0);
         const double specs = (V == 1 && inplace) ? 1.0 : 1.0 + V;   // spectra alive in an iteration
         const double per_frame = (specs * 2.0 * n_spec() + (1.0 + V) * n_img()) * esize(dtype);
         int c = (int)(budget_mb * 1048576.0 / per_frame);
@@ -240,9 +251,18 @@ struct rl_deconv {
         return c;
     }
     int start_estimate_chunk(int f0, int nf) {
-        HIP_TRY(aux_fill(dtype, off(est, (size_t)f0 * n_img()), (size_t)nf * n_img(), 1.0, ctx->stream));
+        HIP_TRY(aux_fill(dtype, off(est, (size_t)f0 * n_img()), (size_t)nf * n_img(), 1.0, cur()));
         RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, off(spec_a, (size_t)f0 * n_spec() * 2), off(est, (size_t)f0 * n_img()),
                    nullptr, nullptr));
+        return RL_OK;
+    }
+    int ensure_lanes() {
+        if (fork) return RL_OK;
+        HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int l = 0; l < lanes; ++l) {
+            HIP_TRY(hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&lane_done[l], hipEventDisableTiming));
+        }
         return RL_OK;
     }
     int iterate_chunk(int f0, int nf) {
@@ -285,11 +305,28 @@ struct rl_deconv {
     // (optionally restart from est = 1 and) run k iterations, chunk by chunk
     int run_iterations(int k, bool restart) {
         const int cf = chunk_frames();
-        for (int f0 = 0; f0 < B; f0 += cf) {
-            const int nf = f0 + cf <= B ? cf : B - f0;
-            if (restart) RL_TRY(start_estimate_chunk(f0, nf));
-            for (int i = 0; i < k; ++i) RL_TRY(iterate_chunk(f0, nf));
+        const int slices = (B + cf - 1) / cf;
+        const int nl = slices < lanes ? slices : lanes;
+        if (nl > 1) {
+            RL_TRY(ensure_lanes());
+            HIP_TRY(hipEventRecord(fork, ctx->stream));
+            for (int l = 0; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(lane_stream[l], fork, 0));
         }
+        int rc = RL_OK;
+        for (int sl = 0, f0 = 0; f0 < B && rc == RL_OK; f0 += cf, ++sl) {
+            const int nf = f0 + cf <= B ? cf : B - f0;
+            active = nl > 1 ? lane_stream[sl % nl] : nullptr;
+            if (restart) rc = start_estimate_chunk(f0, nf);
+            for (int i = 0; i < k && rc == RL_OK; ++i) rc = iterate_chunk(f0, nf);
+        }
+        active = nullptr;
+        if (nl > 1) {   // join, also on errors: the context's stream continues after every lane
+            for (int l = 0; l < nl; ++l) {
+                HIP_TRY(hipEventRecord(lane_done[l], lane_stream[l]));
+                HIP_TRY(hipStreamWaitEvent(ctx->stream, lane_done[l], 0));
+            }
+        }
+        RL_TRY(rc);
         if (restart) {
             est_ready = true;
             spec_valid = true;
@@ -366,6 +403,11 @@ int rl_deconv_destroy(rl_deconv* h) {
         if (b) hipFree(b);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->fork) hipEventDestroy(h->fork);
+    for (int l = 0; l < rl_deconv::kMaxLanes; ++l) {
+        if (h->lane_done[l]) hipEventDestroy(h->lane_done[l]);
+        if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]);
+    }
     delete h;
     return RL_OK;
 }
@@ -450,6 +492,11 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
     if (getenv("RLSTED_STREAM")) h->streaming = atoi(getenv("RLSTED_STREAM"));
     if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
+    if (getenv("RLSTED_LANES")) {
+        h->lanes = atoi(getenv("RLSTED_LANES"));
+        if (h->lanes < 1) h->lanes = 1;
+        if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
+    }
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     int r = deconv_build(h, psfs);
     if (r != RL_OK) {

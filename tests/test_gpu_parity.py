@@ -209,7 +209,8 @@ def test_many_frames_persistent_column_kernel_orders(lib, golden):
 def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatch):
     """The RL loop has switchable kernel flavours (read from the environment when a plan is
     made): streaming = persistent prefetching column / RATIO / UPDATE kernels (RLSTED_STREAM bit
-    mask), in place = single-view iterations entirely in spec_a (RLSTED_INPLACE).  Every
+    mask), in place = single-view iterations entirely in spec_a (RLSTED_INPLACE), the batch cut
+    into slices (RLSTED_CHUNK_MB) that are iterated on RLSTED_LANES concurrent streams.  Every
     combination must give the default's result (same arithmetic, schedule and buffers differ;
     only the compiler's fma contraction may differ between two instantiations) and the oracle's.
     B = 19 frames of 512x512: several work items per persistent workgroup, an item count that is
@@ -224,9 +225,14 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
         d.iterate()
     results = {}
     noisy = None
-    for stream, inplace in (('0', '1'), ('7', '1'), ('7', '0'), ('0', '0'), ('5', '1'), ('2', '0')):
+    # (streaming mask, in place, concurrent slice streams, slice budget in MB: 10 MB = 3 frames)
+    for stream, inplace, lanes, mb in (('0', '1', '2', '108'), ('7', '1', '2', '108'), ('7', '0', '1', '10'),
+                                       ('0', '0', '2', '10'), ('5', '1', '4', '10'), ('2', '0', '3', '20'),
+                                       ('0', '1', '1', '100000')):
         monkeypatch.setenv('RLSTED_STREAM', stream)
         monkeypatch.setenv('RLSTED_INPLACE', inplace)
+        monkeypatch.setenv('RLSTED_LANES', lanes)
+        monkeypatch.setenv('RLSTED_CHUNK_MB', mb)
         plan = lib.DeconvPlan(psf, B, 512, 512, dtype=dtype)
         plan.set_object(objs, 8e11)
         if noisy is None:
@@ -235,9 +241,9 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
             noisy[:2, 0] = np.array(d.noisy_measurement)[0]       # frames 0, 1: the oracle's draw
         plan.set_measurement(noisy)
         plan.iterate(K)
-        results[(stream, inplace)] = plan.estimate()
+        results[(stream, inplace, lanes, mb)] = plan.estimate()
         del plan
-    ref = results[('0', '1')]
+    ref = results[('0', '1', '2', '108')]
     assert max_rel(ref[:2], d.estimate) < tol
     for key, est in results.items():
         assert max_rel(est, ref) < (2e-6 if dtype == 'f32' else 1e-13), key
