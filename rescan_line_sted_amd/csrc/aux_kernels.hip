@@ -65,8 +65,8 @@ __global__ void k_psf_dft_cols(const double2* __restrict__ s1, const double2* __
 // visits), fills it through an LDS counter and publishes the fill level in counts[].
 template <typename T>
 __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
-                               unsigned long long seed, int rng_kind, unsigned* __restrict__ list, unsigned seg_cap,
-                               unsigned* __restrict__ counts) {
+                               unsigned image0, unsigned long long seed, int rng_kind, unsigned* __restrict__ list,
+                               unsigned seg_cap, unsigned* __restrict__ counts) {
     __shared__ unsigned fill;
     if (threadIdx.x == 0) fill = 0;
     __syncthreads();
@@ -79,7 +79,7 @@ __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ 
             continue;
         }
         double k;
-        if (philox_poisson_fast(lam, seed, (unsigned)(i / n_pix), (unsigned)(i % n_pix), &k)) noisy[i] = (T)(k + 1e-9);
+        if (philox_poisson_fast(lam, seed, image0 + (unsigned)(i / n_pix), (unsigned)(i % n_pix), &k)) noisy[i] = (T)(k + 1e-9);
         else seg[atomicAdd(&fill, 1u)] = (unsigned)i;
     }
     __syncthreads();
@@ -87,14 +87,14 @@ __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ 
 }
 
 template <typename T>
-__global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix,
+__global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned image0,
                                unsigned long long seed, const unsigned* __restrict__ list, unsigned seg_cap,
                                const unsigned* __restrict__ counts) {
     const unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
     const unsigned n = counts[blockIdx.x];
     for (unsigned q = threadIdx.x; q < n; q += blockDim.x) {
         const unsigned i = seg[q];
-        noisy[i] = (T)(philox_poisson((double)noiseless[i], seed, i / n_pix, i % n_pix) + 1e-9);
+        noisy[i] = (T)(philox_poisson((double)noiseless[i], seed, image0 + i / n_pix, i % n_pix) + 1e-9);
     }
 }
 
@@ -156,7 +156,7 @@ hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev
     return hipGetLastError();
 }
 
-hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img,
+hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s) {
     const size_t total = (size_t)n_pix * n_img;
     if (total >= 0xffffffffull) return hipErrorInvalidValue;      // 32-bit work-list entries
@@ -166,11 +166,11 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
     unsigned* list = (unsigned*)list_ws;
     unsigned* counts = list + (size_t)seg_cap * g;
     if (dtype == DT_F32) {
-        k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, seed, rng_kind, list, seg_cap, counts);
-        if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, seed, list, seg_cap, counts);
+        k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, image0, seed, rng_kind, list, seg_cap, counts);
+        if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, image0, seed, list, seg_cap, counts);
     } else {
-        k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, seed, rng_kind, list, seg_cap, counts);
-        if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, seed, list, seg_cap, counts);
+        k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, image0, seed, rng_kind, list, seg_cap, counts);
+        if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, image0, seed, list, seg_cap, counts);
     }
     return hipGetLastError();
 }

@@ -11,9 +11,11 @@ hipError_t aux_fill(int dtype, void* p, size_t n, double value, hipStream_t s);
 hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev, const void* wy_dev, void* s1_dev,
                             void* out, int n_psf, int py, int px, int ly, int lx, int kx, int pitch, int transposed,
                             hipStream_t s);
-// list_ws: device scratch of at least aux_poisson_workspace_bytes(n_pix * n_img) bytes
+// list_ws: device scratch of at least aux_poisson_workspace_bytes(n_pix * n_img) bytes.
+// image0: index of the first image in the Philox counter (the draws of an image do not depend on
+// which slice of the batch a launch covers).
 size_t aux_poisson_workspace_bytes(size_t total_pixels);
-hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img,
+hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s);
 // float64 stack [frames][n] (device) -> plan dtype, each frame scaled to sum target[f]
 // (target / sums: device arrays of `frames` doubles; target == nullptr: no scaling)

@@ -91,6 +91,8 @@ struct rl_deconv {
     hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
     hipStream_t active = nullptr;                     // stream the kernel launch helpers use
+    void* slice_ws = nullptr;                         // per-slice Poisson work lists of run_cycle()
+    size_t slice_ws_bytes = 0, slice_ws_stride = 0;
     hipStream_t cur() const { return active ? active : ctx->stream; }
     bool inplace = true;     // single-view RL iterations entirely in spec_a (RLSTED_INPLACE=0: spec_a -> spec_b -> spec_a)
     bool est_ready = false;    // est holds a valid estimate
@@ -302,8 +304,20 @@ struct rl_deconv {
         ++iterations;
         return RL_OK;
     }
-    // (optionally restart from est = 1 and) run k iterations, chunk by chunk
-    int run_iterations(int k, bool restart) {
+    // noiseless = H(obj) on a slice
+    int forward_slice(int f0, int nf) {
+        void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
+        void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
+        RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, sa, off(obj, (size_t)f0 * n_img()), nullptr, nullptr));
+        RL_TRY(col(sa, sb, nf, true));
+        RL_TRY(row(ROW_INV, (unsigned)(nf * V), sb, nullptr, nullptr, off(noiseless, (size_t)f0 * V * n_img()), nullptr));
+        return RL_OK;
+    }
+    // one whole simulate + deconvolve cycle, slice by slice
+    int run_cycle(int k, int rng_kind, uint64_t seed) { return run_slices(k, true, true, rng_kind, seed); }
+    // (optionally restart from est = 1 and) run k iterations, slice by slice
+    int run_iterations(int k, bool restart) { return run_slices(k, restart, false, 0, 0); }
+    int run_slices(int k, bool restart, bool simulate, int rng_kind, uint64_t seed) {
         const int cf = chunk_frames();
         const int slices = (B + cf - 1) / cf;
         const int nl = slices < lanes ? slices : lanes;
@@ -312,11 +326,32 @@ struct rl_deconv {
             HIP_TRY(hipEventRecord(fork, ctx->stream));
             for (int l = 0; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(lane_stream[l], fork, 0));
         }
+        if (simulate) {   // one Poisson work list per slice: slices on different lanes run at the same time
+            const size_t stride = (aux_poisson_workspace_bytes((size_t)cf * V * n_img()) + 255) / 256 * 256;
+            if (slice_ws_bytes < stride * slices) {
+                HIP_TRY(hipDeviceSynchronize());
+                if (slice_ws) HIP_TRY(hipFree(slice_ws));
+                slice_ws = nullptr;
+                HIP_TRY(hipMalloc(&slice_ws, stride * slices));
+                bytes += stride * slices - slice_ws_bytes;
+                slice_ws_bytes = stride * slices;
+            }
+            slice_ws_stride = stride;
+        }
         int rc = RL_OK;
         for (int sl = 0, f0 = 0; f0 < B && rc == RL_OK; f0 += cf, ++sl) {
             const int nf = f0 + cf <= B ? cf : B - f0;
             active = nl > 1 ? lane_stream[sl % nl] : nullptr;
-            if (restart) rc = start_estimate_chunk(f0, nf);
+            if (simulate) {
+                rc = forward_slice(f0, nf);
+                if (rc == RL_OK) {
+                    void* ws = (char*)slice_ws + (size_t)sl * slice_ws_stride;   // this slice's Poisson work list
+                    hipError_t e = aux_poisson(dtype, off(noiseless, (size_t)f0 * V * n_img()), off(meas, (size_t)f0 * V * n_img()),
+                                               (unsigned)n_img(), (unsigned)(nf * V), (unsigned)(f0 * V), seed, rng_kind, ws, cur());
+                    if (e != hipSuccess) rc = fail(RL_ERR_HIP, std::string("Poisson kernels: ") + hipGetErrorString(e));
+                }
+            }
+            if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf);
             for (int i = 0; i < k && rc == RL_OK; ++i) rc = iterate_chunk(f0, nf);
         }
         active = nullptr;
@@ -398,7 +433,7 @@ int rl_deconv_destroy(rl_deconv* h) {
     if (!h) return RL_OK;
     hipSetDevice(h->ctx->device);
     void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
-                    h->stage_dev, h->stage_aux};
+                    h->stage_dev, h->stage_aux, h->slice_ws};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -540,7 +575,7 @@ int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed) {
     if (!h->have_obj) return fail(RL_ERR_STATE, "rl_deconv_set_object has not been called");
     if (rng_kind != RL_RNG_NONE && rng_kind != RL_RNG_PHILOX) return fail(RL_ERR_INVALID, "unknown rng_kind");
     HIP_TRY(hipSetDevice(h->ctx->device));
-    HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), seed, rng_kind,
+    HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 0, seed, rng_kind,
                         h->scratch, h->ctx->stream));
     HIP_TRY(hipStreamSynchronize(h->ctx->stream));
     h->have_meas = true;
@@ -636,11 +671,10 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     hipStream_t s = h->ctx->stream;
     HIP_TRY(hipEventRecord(h->ev0, s));
     for (int r = 0; r < reps; ++r) {
-        RL_TRY(h->forward_object());                                   // noiseless = H(obj)
-        HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V),
-                            seed + (uint64_t)r, rng_kind, h->scratch, s));         // noisy = Poisson(noiseless) + 1e-9
+        // per slice of the batch: noiseless = H(obj), noisy = Poisson(noiseless) + 1e-9, est = 1,
+        // k iterations -- the same values as rl_deconv_simulate + rl_deconv_iterate over the batch
+        RL_TRY(h->run_cycle(k, rng_kind, seed + (uint64_t)r));
         h->have_meas = true;
-        RL_TRY(h->run_iterations(k, true));                            // est = 1, then k iterations (chunked)
     }
     HIP_TRY(hipEventRecord(h->ev1, s));
     HIP_TRY(hipEventSynchronize(h->ev1));
@@ -702,7 +736,7 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
                     else RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_b, h->spec_a, nullptr, h->est, h->norm));
                     break;
                 case 4: RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->obj, nullptr, nullptr)); break;
-                case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 1, RL_RNG_PHILOX, h->scratch, s)); break;
+                case 5: HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 0, 1, RL_RNG_PHILOX, h->scratch, s)); break;
             }
         }
         HIP_TRY(hipEventRecord(h->ev1, s));

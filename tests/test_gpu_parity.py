@@ -249,6 +249,29 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
         assert max_rel(est, ref) < (2e-6 if dtype == 'f32' else 1e-13), key
 
 
+@pytest.mark.parametrize('lanes,mb', [('1', '100000'), ('2', '10'), ('3', '7')])
+def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lanes, mb, monkeypatch):
+    """bench.py's timed call (rl_deconv_bench_cycles: forward model, Poisson, est = 1 and K
+    iterations per slice of the batch, slices on concurrent streams) leaves exactly what
+    rl_deconv_simulate + rl_deconv_iterate over the whole batch leave."""
+    monkeypatch.setenv('RLSTED_LANES', lanes)
+    monkeypatch.setenv('RLSTED_CHUNK_MB', mb)
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    rng = np.random.default_rng(17)
+    B, K = 11, 4
+    objs = np.concatenate([astronaut512, rng.random((B - 1, 512, 512)) * 200])
+    a = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
+    a.set_object(objs, 8e11)
+    a.bench_cycles(K, 2, seed=40)                      # two cycles: seeds 40, 41; the last one stays
+    b = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
+    b.set_object(objs, 8e11)
+    b.simulate(seed=41)
+    b.iterate(K)
+    assert np.array_equal(a.noiseless(), b.noiseless())
+    assert np.array_equal(a.measurement(), b.measurement())
+    assert np.array_equal(a.estimate(), b.estimate())
+
+
 # ------------------------------------- BASELINE configs 3 and 5: large images
 def test_2048_line_rescan_batch_vs_oracle(lib, golden):
     """Config 3 shape: synthetic 2048x2048 random object, line-rescan (4 views), a
