@@ -676,11 +676,33 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
 #endif
 constexpr size_t RL_STREAM_SLACK = 16384;   // >= (L - nx) elements of any dtype for the wave-private lengths
 
-template <class Cfg, int Q, int MODE, typename T, class Sync>
-RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
-    static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
-    static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "streaming row pass: RL modes only");
-    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
+// The two half spectra of one row pair: lanes t + 64*it of rows r0 (A) and r0 + 1 (B; row r0
+// again when the pair has one row -- zeroed at the use).  Scalar row bases, no clamps.
+template <class Cfg, typename T>
+struct RowSpectra {
+    static constexpr int NPK = (Cfg::L / 2 + 64) / 64;   // ceil((L/2 + 1) / 64)
+    cx<T> A[NPK], B[NPK];
+    RL_HD void request(const RowParams<T>& p, int by, int r0, unsigned t) {
+        const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * ((size_t)p.ny * p.pitch) + (size_t)r0 * p.pitch;
+        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? p.pitch : 0);
+#pragma unroll
+        for (int it = 0; it < NPK; ++it) {
+            A[it] = sa[t + it * 64];
+            B[it] = sb[t + it * 64];
+        }
+    }
+};
+
+// One row pair of ROW_RATIO / ROW_UPDATE (single view) for a wave: spectra `in` (already
+// requested) -> pack -> inverse -> pointwise -> forward -> split -> store.  by, r0: image and first
+// row (wave uniform); t: lane; tl_: lane index used for LDS addressing; tw: twiddle table (global
+// memory or LDS); `after_pack` runs once `in` has been consumed (the streaming body requests the
+// next item's spectra there).
+template <class Cfg, int MODE, typename T, class Sync, class AfterPack>
+RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, RowSpectra<Cfg, T>& in, LdsView<T, 1> view_lds,
+                    const cx<T>* tw, Sync& sync, AfterPack&& after_pack) {
+    static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "RL modes only");
+    constexpr int NP = Cfg::NP, L = Cfg::L;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     using IL = PassInfo<Cfg, true, NP - 1>;
     using F0 = PassInfo<Cfg, false, 0>;
@@ -688,130 +710,145 @@ RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>
     static_assert(IL::R == F0::R && IL::NB == F0::NB, "inverse must end on the forward's first radix");
     static_assert(!F0::TAIL, "the pass that touches the images must be lane-local");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
-    constexpr int NPK = (L / 2 + 64) / 64;   // ceil((L/2 + 1) / 64)
-    static_assert((size_t)(NB * 64 + (R - 1) * NBF) * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");
+    constexpr int NPK = RowSpectra<Cfg, T>::NPK;
+    const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
+    const int r1 = r0 + 1;
+    const bool ok1 = r1 < p.ny;
+    rl_stamp(sync, 0);
+    // operands of the pointwise stage: measurement (ROW_RATIO) / current estimate (ROW_UPDATE)
+    cx<T> pre[NB * R];
+    T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * p.nx;
+    T* __restrict__ const est1 = est0 + (ok1 ? p.nx : 0);
+    {
+        const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * p.nx : est0;
+        const T* __restrict__ s1 = s0 + (ok1 ? p.nx : 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) pre[nb * R + r] = mk<T>(s0[t + (nb * 64 + r * NBF)], s1[t + (nb * 64 + r * NBF)]);
+    }
+    cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
+    if constexpr (MODE == ROW_UPDATE) {   // requested with the estimate, ahead of the inverse transform: behind it
+                                          // they would cost the pointwise stage an exposed L2 round trip
+        const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
+        const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
+    }
+    // pack the two half spectra into one Hermitian-free complex row
+    fft_sync<Cfg>(sync);   // LDS free
+#pragma unroll
+    for (int it = 0; it < NPK; ++it) {
+        const int kk = tl_ + it * 64;
+        if (kk <= L / 2) {
+            const cx<T> a = in.A[it], b = mk<T>(ok1 ? in.B[it].re : (T)0, ok1 ? in.B[it].im : (T)0);
+            view_lds.at(kk) = mk<T>(a.re - b.im, a.im + b.re);
+            if (kk > 0 && kk < L / 2) view_lds.at(L - kk) = mk<T>(a.re + b.im, b.re - a.im);
+        }
+    }
+    after_pack();
+    fft_sync<Cfg>(sync);
+    rl_stamp(sync, 1);
+    cx<T> v[VMAX];
+    cx<T> tl = mk<T>((T)0, (T)0);
+    run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
+    rl_stamp(sync, 2);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = (int)t + nb * 64;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = nb * R + r;
+            const int i = j + r * NBF;
+            const bool inx = (j < NBF) && (i < p.nx);
+            cx<T> z = mk<T>((T)0, (T)0);
+            const T e0 = v[s].re > (T)0 ? v[s].re : (T)0, e1 = v[s].im > (T)0 ? v[s].im : (T)0;
+            if constexpr (MODE == ROW_RATIO) {
+                z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
+                z.im = inx && ok1 ? rl_div(pre[s].im, e1) : (T)0;
+            } else {
+                z.re = inx ? pre[s].re * rl_div(e0, nrm[s].re) : (T)0;
+                z.im = inx && ok1 ? pre[s].im * rl_div(e1, nrm[s].im) : (T)0;
+                if (inx) est0[t + (nb * 64 + r * NBF)] = z.re;
+                if (inx && ok1) est1[t + (nb * 64 + r * NBF)] = z.im;
+            }
+            v[s] = z;
+        }
+    }
+    rl_stamp(sync, 3);
+    run_passes<Cfg, false, 0, true>(v, tl, tl_, view_lds, tw, sync);
+    rl_stamp(sync, 4);
+    // natural-order spectrum to LDS, then split it into the two rows' half spectra
+    fft_sync<Cfg>(sync);
+    if constexpr (FL::TAIL) view_lds.at((64 + (tl_ & 7)) + bitrev3(tl_ >> 3) * FL::NBF) = tl;
+#pragma unroll
+    for (int nb = 0; nb < FL::NBM; ++nb) {
+        const int j = tl_ + nb * 64;
+        if (j < FL::NBF) {
+#pragma unroll
+            for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, lds_pad(j), r) = v[nb * FL::R + r];
+        }
+    }
+    fft_sync<Cfg>(sync);
+    cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
+    cx<T>* __restrict__ so1 = so0 + p.pitch;
+#pragma unroll
+    for (int it = 0; it < NPK; ++it) {
+        const int kk = tl_ + it * 64;
+        if (kk <= L / 2) {
+            const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
+            so0[t + it * 64] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
+            if (ok1) so1[t + it * 64] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+        }
+    }
+    rl_stamp(sync, 5);
+}
+
+template <class Cfg, int Q, int MODE, typename T, class Sync>
+RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
+    constexpr int LP = LdsLen<Cfg::L>::value;
+    static_assert((size_t)Cfg::L * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");   // overrun < L elements
     const int q = rl_uniform(tid / 64);
     const unsigned t = (unsigned)(tid % 64);
-    const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
     LdsView<T, 1> view_lds{lds + q * LP};
 
     for (int i = tid; i < StreamTw<Cfg>::COUNT; i += 64 * Q) lds[Q * LP + i] = p.tw[i];
 
     const int pairs = (p.ny + 1) / 2;
     const int total = p.frames * pairs, stride = nwg * Q;
-    cx<T> A[NPK], B[NPK];
-    auto request = [&](int item) {   // the two half spectra of row pair `item` (scalar)
-        const int by = item / pairs, r0 = 2 * (item % pairs);
-        const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * simg + (size_t)r0 * p.pitch;
-        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? p.pitch : 0);   // one-row pair: row r0 again, zeroed at the use
-#pragma unroll
-        for (int it = 0; it < NPK; ++it) {
-            A[it] = sa[t + it * 64];
-            B[it] = sb[t + it * 64];
-        }
-    };
+    RowSpectra<Cfg, T> in;
     int item = wg * Q + q;
-    if (item < total) request(item);
+    if (item < total) in.request(p, item / pairs, 2 * (item % pairs), t);
     sync.wg();   // twiddles are in LDS; from here on the waves never meet again
     for (; item < total; item += stride) {
         const cx<T>* tw = lds + stream_launder(Q * LP);
         const int tl_ = RL_STREAM_LAUNDER_LDS ? stream_launder_lane((int)t) : (int)t;   // lane index for LDS addressing
-        const int by = item / pairs, r0 = 2 * (item % pairs), r1 = r0 + 1;
-        const bool ok1 = r1 < p.ny;
-        rl_stamp(sync, 0);
-        // operands of the pointwise stage: measurement (ROW_RATIO) / current estimate (ROW_UPDATE)
-        cx<T> pre[NB * R];
-        T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * p.nx;
-        T* __restrict__ const est1 = est0 + (ok1 ? p.nx : 0);
-        {
-            const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * p.nx : est0;
-            const T* __restrict__ s1 = s0 + (ok1 ? p.nx : 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < R; ++r) pre[nb * R + r] = mk<T>(s0[t + (nb * 64 + r * NBF)], s1[t + (nb * 64 + r * NBF)]);
-        }
-        cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
-        if constexpr (MODE == ROW_UPDATE) {   // requested with the estimate, ahead of the inverse transform: behind it
-                                              // they would cost the pointwise stage an exposed L2 round trip
-            const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
-            const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
-        }
-        // pack the two half spectra into one Hermitian-free complex row
-        fft_sync<Cfg>(sync);   // LDS free
-#pragma unroll
-        for (int it = 0; it < NPK; ++it) {
-            const int kk = tl_ + it * 64;
-            if (kk <= L / 2) {
-                const cx<T> a = A[it], b = mk<T>(ok1 ? B[it].re : (T)0, ok1 ? B[it].im : (T)0);
-                view_lds.at(kk) = mk<T>(a.re - b.im, a.im + b.re);
-                if (kk > 0 && kk < L / 2) view_lds.at(L - kk) = mk<T>(a.re + b.im, b.re - a.im);
-            }
-        }
-        // lands while this item is transformed; unconditional (the last item re-requests itself) so
-        // that the waits of the pointwise stage can count past it
-        request(item + stride < total ? item + stride : item);
-        fft_sync<Cfg>(sync);
-        rl_stamp(sync, 1);
-        cx<T> v[VMAX];
-        cx<T> tl = mk<T>((T)0, (T)0);
-        run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
-        rl_stamp(sync, 2);
-
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int j = (int)t + nb * 64;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = nb * R + r;
-                const int i = j + r * NBF;
-                const bool inx = (j < NBF) && (i < p.nx);
-                cx<T> z = mk<T>((T)0, (T)0);
-                const T e0 = v[s].re > (T)0 ? v[s].re : (T)0, e1 = v[s].im > (T)0 ? v[s].im : (T)0;
-                if constexpr (MODE == ROW_RATIO) {
-                    z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
-                    z.im = inx && ok1 ? rl_div(pre[s].im, e1) : (T)0;
-                } else {
-                    z.re = inx ? pre[s].re * rl_div(e0, nrm[s].re) : (T)0;
-                    z.im = inx && ok1 ? pre[s].im * rl_div(e1, nrm[s].im) : (T)0;
-                    if (inx) est0[t + (nb * 64 + r * NBF)] = z.re;
-                    if (inx && ok1) est1[t + (nb * 64 + r * NBF)] = z.im;
-                }
-                v[s] = z;
-            }
-        }
-        rl_stamp(sync, 3);
-        run_passes<Cfg, false, 0, true>(v, tl, tl_, view_lds, tw, sync);
-        rl_stamp(sync, 4);
-        // natural-order spectrum to LDS, then split it into the two rows' half spectra
-        fft_sync<Cfg>(sync);
-        if constexpr (FL::TAIL) view_lds.at((64 + (tl_ & 7)) + bitrev3(tl_ >> 3) * FL::NBF) = tl;
-#pragma unroll
-        for (int nb = 0; nb < FL::NBM; ++nb) {
-            const int j = tl_ + nb * 64;
-            if (j < FL::NBF) {
-#pragma unroll
-                for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, lds_pad(j), r) = v[nb * FL::R + r];
-            }
-        }
-        fft_sync<Cfg>(sync);
-        cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
-        cx<T>* __restrict__ so1 = so0 + p.pitch;
-#pragma unroll
-        for (int it = 0; it < NPK; ++it) {
-            const int kk = tl_ + it * 64;
-            if (kk <= L / 2) {
-                const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
-                so0[t + it * 64] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
-                if (ok1) so1[t + it * 64] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
-            }
-        }
-        rl_stamp(sync, 5);
+        // the next item's spectra land while this one is transformed; unconditional (the last item
+        // re-requests itself) so that the waits of the pointwise stage can count past the loads
+        const int next = item + stride < total ? item + stride : item;
+        row_item<Cfg, MODE>(p, t, tl_, item / pairs, 2 * (item % pairs), in, view_lds, tw, sync,
+                            [&] { in.request(p, next / pairs, 2 * (next % pairs), t); });
     }
+}
+
+// Tiled flavour of the same item code: one row pair per wave, Q waves per workgroup, grid
+// (ceil(pairs / Q), images); twiddles from global memory (L1).  Replaces rowpass_body for the
+// single-view RL modes of the wave-private lengths: scalar row bases and unconditional loads
+// save ~15 % of its VALU instructions and all of its per-load exec branches.
+template <class Cfg, int Q, int MODE, typename T, class Sync>
+RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "lean row body needs wave-private transforms");
+    constexpr int LP = LdsLen<Cfg::L>::value;
+    const int q = rl_uniform(tid / 64);
+    const unsigned t = (unsigned)(tid % 64);
+    const int r0 = 2 * (bx * Q + q);
+    if (r0 >= p.ny) return;   // whole wave; the wave-private row kernels have no workgroup barrier
+    RowSpectra<Cfg, T> in;
+    in.request(p, by, r0, t);
+    row_item<Cfg, MODE>(p, t, (int)t, by, r0, in, LdsView<T, 1>{lds + q * LP}, p.tw, sync, [] {});
 }
 
 }  // namespace rl

@@ -12,6 +12,9 @@
 #ifndef RL_ROW_MIN_WAVES
 #define RL_ROW_MIN_WAVES 5
 #endif
+#ifndef RL_ROW_LEAN
+#define RL_ROW_LEAN 1
+#endif
 #ifndef RL_COL_MIN_WAVES
 #define RL_COL_MIN_WAVES 1
 #endif
@@ -61,7 +64,14 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (sizeof(T) == 4 && MODE 
     k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    rowpass_body<typename CfgFor<L>::Cfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    using KCfg = typename CfgFor<L>::Cfg;
+    // single-view RL modes of the wave-private lengths: the lean item code (scalar row bases,
+    // unconditional loads).  RATIO treats every (frame, view) image on its own, so it always qualifies.
+    constexpr bool LEAN = RL_ROW_LEAN && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
+    if constexpr (LEAN)
+        rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+    else
+        rowpass_body<KCfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 
 // ---- streaming kernels (wave-private lengths): persistent workgroups, twiddles in LDS ----

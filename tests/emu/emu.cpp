@@ -142,6 +142,12 @@ static int row_m(const RowParams<T>& p, int gy) {
     run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsLen<L>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
+                 if constexpr (WavePrivate<Cfg>::value && (MODE == ROW_RATIO || MODE == ROW_UPDATE)) {
+                     if (MODE == ROW_RATIO || p.V == 1) {   // same dispatch as k_rowpass (LEAN) in fft_kernels.hip
+                         rowlean_body<Cfg, Q, MODE, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                         return;
+                     }
+                 }
                  if (MULTI && p.V == 1)   // same dispatch as launch_row_m in fft_kernels.hip
                      rowpass_body<Cfg, Q, MODE, MULTI, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
                  else

@@ -1,0 +1,76 @@
+// valu_probe.hip -- developer tool: issue rate of plain vs packed f32 VALU ops with several waves
+// per SIMD (does v_pk_add_f32 / v_pk_fma_f32 retire two results per lane in the time of one?).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k(float* out, int iters) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    const float c = 1.0001f, d = 0.5f;
+    const float2v pc = {1.0001f, 0.9999f}, pd = {0.5f, 0.25f};
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0) {        // 8 independent v_fma_f32
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+        } else if (MODE == 1) { // 8 independent v_pk_fma_f32
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pc), "v"(pd));
+        } else if (MODE == 2) { // 8 independent v_add_f32
+            asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(d));
+        } else if (MODE == 3) { // 8 independent v_pk_add_f32
+            asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                         "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pd));
+        } else if (MODE == 4) { // 8 independent v_add_u32 (integer / address arithmetic)
+            asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                         "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(d));
+        } else {                // packed add with a swapped, half-negated operand: a + i*b for complex pairs
+            asm volatile("v_pk_add_f32 %0, %0, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %1, %1, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n"
+                         "v_pk_add_f32 %2, %2, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %3, %3, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n"
+                         "v_pk_add_f32 %4, %4, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %5, %5, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n"
+                         "v_pk_add_f32 %6, %6, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %7, %7, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pd));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+}
+
+int main() {
+    float* out; CHECK(hipMalloc(&out, 256 * 1024 * 64 * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int iters = 20000;
+    const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_pk_add_f32", "v_add_u32", "v_pk_add_f32 op_sel/neg"};
+    for (int wgs_per_cu : {1, 2, 4, 5}) {           // 4 waves per WG -> 1, 2, 4, 5 waves per SIMD
+        printf("%d wave(s) per SIMD:\n", wgs_per_cu);
+        for (int mode = 0; mode < 6; ++mode) {
+            float ms = 0;
+            const int grid = 256 * wgs_per_cu;
+            for (int rep = 0; rep < 2; ++rep) {
+                CHECK(hipEventRecord(e0));
+                switch (mode) {
+                    case 0: k<0><<<grid, 256>>>(out, iters); break;
+                    case 1: k<1><<<grid, 256>>>(out, iters); break;
+                    case 2: k<2><<<grid, 256>>>(out, iters); break;
+                    case 3: k<3><<<grid, 256>>>(out, iters); break;
+                    case 4: k<4><<<grid, 256>>>(out, iters); break;
+                    default: k<5><<<grid, 256>>>(out, iters); break;
+                }
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipGetLastError());
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            const double instr = (double)iters * 8 * wgs_per_cu;   // wave-instructions per SIMD
+            printf("   %-26s %.3f ms  -> %.2f ns per wave-instruction per SIMD (%.2f cycles at 2.4 GHz)\n", names[mode], ms,
+                   ms * 1e6 / instr, ms * 1e6 / instr * 2.4);
+        }
+    }
+    return 0;
+}
