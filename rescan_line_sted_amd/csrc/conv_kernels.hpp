@@ -674,6 +674,9 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
 #ifndef RL_STREAM_LAUNDER_LDS
 #define RL_STREAM_LAUNDER_LDS 1   // 1: LDS lane addresses are recomputed per item (fewer registers, more VALU)
 #endif
+#ifndef RL_LEAN_NRM_EARLY
+#define RL_LEAN_NRM_EARLY 0   // tiled lean ROW_UPDATE: normaliser loads behind the inverse transform (fewer registers)
+#endif
 constexpr size_t RL_STREAM_SLACK = 16384;   // >= (L - nx) elements of any dtype for the wave-private lengths
 
 // The two half spectra of one row pair: lanes t + 64*it of rows r0 (A) and r0 + 1 (B; row r0
@@ -698,7 +701,7 @@ struct RowSpectra {
 // row (wave uniform); t: lane; tl_: lane index used for LDS addressing; tw: twiddle table (global
 // memory or LDS); `after_pack` runs once `in` has been consumed (the streaming body requests the
 // next item's spectra there).
-template <class Cfg, int MODE, typename T, class Sync, class AfterPack>
+template <class Cfg, int MODE, bool NRM_EARLY, typename T, class Sync, class AfterPack>
 RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, RowSpectra<Cfg, T>& in, LdsView<T, 1> view_lds,
                     const cx<T>* tw, Sync& sync, AfterPack&& after_pack) {
     static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "RL modes only");
@@ -727,16 +730,20 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
 #pragma unroll
             for (int r = 0; r < R; ++r) pre[nb * R + r] = mk<T>(s0[t + (nb * 64 + r * NBF)], s1[t + (nb * 64 + r * NBF)]);
     }
+    // normaliser values (ROW_UPDATE): all of them requested before the first store of the pointwise
+    // stage (see rowpass_body).  NRM_EARLY: together with the estimate, ahead of the inverse
+    // transform, so the pointwise stage never waits for L2 -- at the price of NB*R more live
+    // registers through the transform; otherwise right behind it.
     cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
-    if constexpr (MODE == ROW_UPDATE) {   // requested with the estimate, ahead of the inverse transform: behind it
-                                          // they would cost the pointwise stage an exposed L2 round trip
+    auto request_norm = [&] {
         const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
         const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
-    }
+    };
+    if constexpr (MODE == ROW_UPDATE && NRM_EARLY) request_norm();
     // pack the two half spectra into one Hermitian-free complex row
     fft_sync<Cfg>(sync);   // LDS free
 #pragma unroll
@@ -755,6 +762,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
     cx<T> tl = mk<T>((T)0, (T)0);
     run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
     rl_stamp(sync, 2);
+    if constexpr (MODE == ROW_UPDATE && !NRM_EARLY) request_norm();
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int j = (int)t + nb * 64;
@@ -829,7 +837,7 @@ RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>
         // the next item's spectra land while this one is transformed; unconditional (the last item
         // re-requests itself) so that the waits of the pointwise stage can count past the loads
         const int next = item + stride < total ? item + stride : item;
-        row_item<Cfg, MODE>(p, t, tl_, item / pairs, 2 * (item % pairs), in, view_lds, tw, sync,
+        row_item<Cfg, MODE, true>(p, t, tl_, item / pairs, 2 * (item % pairs), in, view_lds, tw, sync,
                             [&] { in.request(p, next / pairs, 2 * (next % pairs), t); });
     }
 }
@@ -848,7 +856,7 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     if (r0 >= p.ny) return;   // whole wave; the wave-private row kernels have no workgroup barrier
     RowSpectra<Cfg, T> in;
     in.request(p, by, r0, t);
-    row_item<Cfg, MODE>(p, t, (int)t, by, r0, in, LdsView<T, 1>{lds + q * LP}, p.tw, sync, [] {});
+    row_item<Cfg, MODE, RL_LEAN_NRM_EARLY != 0>(p, t, (int)t, by, r0, in, LdsView<T, 1>{lds + q * LP}, p.tw, sync, [] {});
 }
 
 }  // namespace rl

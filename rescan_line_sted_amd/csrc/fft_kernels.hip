@@ -12,6 +12,9 @@
 #ifndef RL_ROW_MIN_WAVES
 #define RL_ROW_MIN_WAVES 5
 #endif
+#ifndef RL_UPD_MIN_WAVES
+#define RL_UPD_MIN_WAVES 1
+#endif
 #ifndef RL_ROW_LEAN
 #define RL_ROW_LEAN 1
 #endif
@@ -59,8 +62,17 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && WaveP
         colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
 
+// waves per SIMD requested from the register allocator (f32, wave-private lengths)
+template <int L, int MODE, bool ONEV, typename T>
+constexpr int row_min_waves() {
+    if (sizeof(T) != 4 || !WavePrivate<typename CfgFor<L>::Cfg>::value) return 1;
+    if (MODE == ROW_RATIO) return RL_ROW_MIN_WAVES;
+    if (MODE == ROW_UPDATE && ONEV) return RL_UPD_MIN_WAVES;
+    return 1;
+}
+
 template <int L, int Q, int MODE, bool ONEV, typename T>
-__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (sizeof(T) == 4 && MODE == ROW_RATIO && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_ROW_MIN_WAVES : 1)
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, ONEV, T>()))
     k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
