@@ -58,7 +58,8 @@ def main():
     if 'colconv' in res:   # the H and H_t column passes are the same kernel
         res['colconv_H'] = res['colconv_Ht'] = res['colconv']
     if 'rowpass_FWD' in res:
-        res['_calibration'] = {'rowpass_FWD_must_read_bytes': batch * 512 * 512 * 4,
+        # rowpass_FWD's most frequent shape is the slice too (est = 1 -> spectrum, H(obj) per slice)
+        res['_calibration'] = {'rowpass_FWD_must_read_bytes': fl * 512 * 512 * 4,
                                'rowpass_FWD_fetch_reported_bytes': res['rowpass_FWD']['fetch_kb_reported'] * 1024}
     json.dump(res, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in res.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v}))
