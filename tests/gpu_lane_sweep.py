@@ -8,6 +8,10 @@ import bench
 from rescan_line_sted_amd import _lib
 obj, psf, brightness = bench.workload()
 B = 256
+if os.environ.get('PSFSET'):          # e.g. PSFSET=2p0x_lr/line_sted_psfs B=64
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
+    psf = [p[None] for p in g[os.environ['PSFSET']][:, 0]]
+    B = int(os.environ.get('B', '64'))
 for lanes in (sys.argv[1].split(',') if len(sys.argv) > 1 else ('1', '2', '3', '4')):
     for mb in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('72', '108', '144', '216', '288')):
         os.environ['RLSTED_LANES'] = lanes
