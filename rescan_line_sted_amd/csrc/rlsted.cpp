@@ -432,6 +432,10 @@ int rl_ctx_synchronize(rl_ctx* c) {
 int rl_deconv_destroy(rl_deconv* h) {
     if (!h) return RL_OK;
     hipSetDevice(h->ctx->device);
+    // nothing of this plan may still be running when its buffers go away (slice streams included)
+    hipStreamSynchronize(h->ctx->stream);
+    for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
+        if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
     void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->slice_ws};
     for (void* b : bufs)
