@@ -53,7 +53,15 @@ struct ColParams {
 };
 
 template <class Cfg, int C, typename T, class Sync>
-RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync_in) {
+    // The threads of one transform are tid = c + C*t here (consecutive threads = consecutive
+    // columns, for coalescing): they are spread over the waves of the workgroup whatever T is,
+    // so the inter-pass exchanges always need workgroup barriers.
+    struct WorkgroupSync {
+        Sync& s;
+        RL_HD void wg() const { s.wg(); }
+        RL_HD void wave() const { s.wg(); }
+    } sync{sync_in};
     constexpr int NP = Cfg::NP;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     const int c = tid % C, t = tid / C;

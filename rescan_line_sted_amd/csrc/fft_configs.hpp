@@ -19,12 +19,19 @@ struct CfgFor<64> {   // unit-test size
 };
 template <>
 struct CfgFor<192> {  // 128 + 53
-    using Cfg = FftCfg<192, 64, 3, 8, 8>;     // T == 64: wave-private transforms
-    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
+    // 16 lanes per transform, four transforms per wave: every lane has a butterfly in the
+    // radix-12 pass and 12 of 16 in the radix-16 pass, against 24 of 64 in the radix-8 passes of
+    // (3,8,8) on a whole wave.  Measured at 128x128, f32: +25 % (one view), +8 % (four views, which
+    // lose the fused multi-view column modes that exist for T == 64 only).  Row kernels still
+    // exchange through LDS with wave-level ordering only (WaveLocal).
+    using Cfg = FftCfg<192, 16, 12, 16>;
+    static constexpr int C32 = 32, C64 = 16, Q32 = 16, Q64 = 16;
 };
 template <>
 struct CfgFor<256> {  // 160 + 53
-    using Cfg = FftCfg<256, 64, 4, 8, 8>;     // wave-private
+    // wave-private; (16,16) on 16 lanes measures +14 % for one view but -9 % for four (no fused
+    // multi-view column modes), so the whole-wave geometry stays
+    using Cfg = FftCfg<256, 64, 4, 8, 8>;
     static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
 };
 template <>

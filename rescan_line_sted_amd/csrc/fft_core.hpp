@@ -327,6 +327,14 @@ template <class Cfg>
 struct WavePrivate {
     static constexpr bool value = (Cfg::T == 64);
 };
+// The same holds when several whole transforms share a wavefront (T divides 64 and workgroups are
+// built of whole transforms in thread order): the T threads of a transform sit in one wave, so its
+// inter-pass exchanges need wave-level ordering only.  WavePrivate (T == 64) additionally selects
+// the kernels written for one transform per wave (cross-lane tails, scalar row bases, streaming).
+template <class Cfg>
+struct WaveLocal {
+    static constexpr bool value = (64 % Cfg::T == 0);
+};
 
 // A value that is the same in every lane of the wavefront, moved to a scalar register so that
 // everything derived from it (row / image base addresses) is scalar arithmetic and the memory
@@ -350,7 +358,7 @@ RL_HD void rl_stamp(Sync& s, int k) { rl_stamp_impl(s, k, 0); }
 
 template <class Cfg, class Sync>
 RL_HD void fft_sync(Sync& sync) {
-    if constexpr (WavePrivate<Cfg>::value) sync.wave();
+    if constexpr (WaveLocal<Cfg>::value) sync.wave();
     else sync.wg();
 }
 

@@ -229,12 +229,12 @@ def test_richardson_lucy_matches_oracle(emu, dtype, tol):
 
 
 def test_multi_view_column_modes_on_wave_private_length(emu):
-    """Ly = 192 (wave private): H with one shared forward transform, H_t summed in the
+    """Ly = 256 (wave private): H with one shared forward transform, H_t summed in the
     Fourier domain, and the fused RL iteration, against the oracle."""
     rng = np.random.default_rng(6)
     ny, nx = 150, 40
     psfs = [rng.random((1, 9, 5)), rng.random((1, 7, 7)), rng.random((1, 11, 3))]
-    pl = EmuPlan(emu, psfs, ny, nx, 192, 64)
+    pl = EmuPlan(emu, psfs, ny, nx, 256, 64)
     assert pl.transposed == 1
     x = rng.random((2, ny, nx))
     got, _ = pl.H(x)                                        # COL_H_MULTI
@@ -283,7 +283,7 @@ def test_streaming_bodies_match_tiled_bodies(emu, nwg):
     for _ in range(2):
         d.iterate()
     meas = np.array(d.noisy_measurement)[0][:, None]                                    # (B=2, V=1, ny, nx)
-    pl = EmuPlan(emu, psfs, ny, nx, 192, 192)
+    pl = EmuPlan(emu, psfs, ny, nx, 256, 256)          # a wave-private length on both axes
     try:
         emu.emu_set_stream(0)
         tiled, _ = pl.rl(meas, 2)
