@@ -15,6 +15,9 @@
 #ifndef RL_UPD_MIN_WAVES
 #define RL_UPD_MIN_WAVES 1
 #endif
+#ifndef RL_ROW_XCD_REMAP
+#define RL_ROW_XCD_REMAP 1
+#endif
 #ifndef RL_ROW_LEAN
 #define RL_ROW_LEAN 1
 #endif
@@ -77,13 +80,30 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
+    // XCD-consistent image placement (pure speed heuristic, as in k_colconv): workgroups are dealt
+    // round-robin over the 8 XCDs, so give each XCD a contiguous range of (image, row group) items --
+    // the same images the column kernel's remap gives it.  A spectrum written by one kernel is then
+    // read by the next one through the same L2 (whose contents survive the kernel boundary:
+    // tools/l2_probe.hip).
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+#if RL_ROW_XCD_REMAP
+    {
+        const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
+        if (total % 8 == 0) {
+            const unsigned lin = by * gx + bx;
+            const unsigned w = (lin % 8) * (total / 8) + lin / 8;
+            bx = w % gx;
+            by = w / gx;
+        }
+    }
+#endif
     // single-view RL modes of the wave-private lengths: the lean item code (scalar row bases,
     // unconditional loads).  RATIO treats every (frame, view) image on its own, so it always qualifies.
     constexpr bool LEAN = RL_ROW_LEAN && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
     if constexpr (LEAN)
-        rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+        rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
-        rowpass_body<KCfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+        rowpass_body<KCfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
 
 // ---- streaming kernels (wave-private lengths): persistent workgroups, twiddles in LDS ----
