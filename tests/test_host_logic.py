@@ -126,3 +126,22 @@ def test_deconvolver_surface_matches_reference(tmp_path):
                                       'steps_per_improved_psf_width', 'relative_error', 'verbose_results',
                                       'verbose_iterations'])):
         assert list(inspect.signature(fn).parameters) == names
+
+
+def test_pmc_traffic_json_is_what_the_tool_makes_of_the_committed_counter_files(tmp_path):
+    """profiles/r01/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from
+    the committed rocprofv3 counter files with tools/pmc_traffic.py."""
+    import json
+    import subprocess
+    import sys
+    prof = os.path.join(ROOT, 'profiles', 'r01')
+    committed = json.load(open(os.path.join(prof, 'pmc_traffic.json')))
+    out = tmp_path / 'traffic.json'
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'),
+                           os.path.join(prof, 'pmc_fetch_size_v5.csv'), os.path.join(prof, 'pmc_write_size_v5.csv'),
+                           str(out), str(committed['frames_per_launch'])], stdout=subprocess.DEVNULL)
+    again = json.load(open(out))
+    assert again == committed
+    # the doubled FETCH_SIZE reproduces the bytes rowpass_FWD must read to within 1 %
+    cal = committed['_calibration']
+    assert abs(2 * cal['rowpass_FWD_fetch_reported_bytes'] / cal['rowpass_FWD_must_read_bytes'] - 1) < 0.01
