@@ -73,6 +73,13 @@ int rl_deconv_set_object(rl_deconv* h, const double* obj, const double* total_br
 /* create_data_from_object (:508-511), second half: noisy = Poisson(noiseless)
  * + 1e-9 drawn on the device.  Counter layout: see DESIGN.md "Device Poisson". */
 int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed);
+
+/* As rl_deconv_simulate, with a Philox key per frame: frame f (all its views v) draws with seed
+ * seeds[f] and image index image_ids[f] * n_psf + v (host arrays of n_frames entries).  A frame's
+ * noise then depends on (seed, image id, pixel) only -- not on the batch it is simulated in, which
+ * is what lets a parameter sweep pack tasks with different seeds into one plan.  With seeds[f] = s
+ * and image_ids[f] = f this is rl_deconv_simulate(h, rng_kind, s).                              */
+int rl_deconv_simulate_keyed(rl_deconv* h, int rng_kind, const uint64_t* seeds, const uint32_t* image_ids);
 /* Inject a measurement [batch][n_psf][ny][nx] instead (load_data_from_tif
  * :514-518, or noise drawn on the host with numpy for figure reproduction).  */
 int rl_deconv_set_measurement(rl_deconv* h, const double* noisy);

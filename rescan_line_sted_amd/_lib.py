@@ -31,6 +31,7 @@ PROTOTYPES = {
     'rl_deconv_info': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_c.c_size_t)]),
     'rl_deconv_set_object': (_i, [_vp, _dp, _dp]),
     'rl_deconv_simulate': (_i, [_vp, _i, _c.c_uint64]),
+    'rl_deconv_simulate_keyed': (_i, [_vp, _i, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32)]),
     'rl_deconv_set_measurement': (_i, [_vp, _dp]),
     'rl_deconv_iterate': (_i, [_vp, _i]),
     'rl_deconv_reset_estimate': (_i, [_vp]),
@@ -198,6 +199,14 @@ class DeconvPlan:
         a, b = _c.c_double(), _c.c_double()
         check(lib.rl_deconv_last_ms(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return {'iterate_ms': a.value, 'simulate_ms': b.value}
+
+    def simulate_keyed(self, seeds, image_ids, rng=RNG_PHILOX):
+        """Poisson noise with a Philox key per frame: frame f draws with seed seeds[f] and image
+        index image_ids[f] * n_psf + view, whatever batch it sits in."""
+        seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.B,)))
+        ids = np.ascontiguousarray(np.broadcast_to(np.asarray(image_ids, dtype=np.uint32), (self.B,)))
+        check(lib.rl_deconv_simulate_keyed(self.handle, rng, seeds.ctypes.data_as(_c.POINTER(_c.c_uint64)),
+                                           ids.ctypes.data_as(_c.POINTER(_c.c_uint32))))
 
     def bench_cycles(self, k, reps, rng=RNG_PHILOX, seed=0):
         ms = _c.c_double()

@@ -54,6 +54,20 @@ __global__ void k_psf_dft_cols(const double2* __restrict__ s1, const double2* __
     }
 }
 
+// Philox key / counter of an image of the launch: one seed and consecutive image indices from
+// image0, or -- frame_seeds != nullptr -- a seed and an image id per frame (V views each), so that
+// a frame's draws do not depend on which batch it was put in.
+struct PoissonKeys {
+    unsigned long long seed0;
+    unsigned image0, V;
+    const unsigned long long* frame_seeds;   // [frames] or nullptr
+    const unsigned* frame_ids;               // [frames] (with frame_seeds)
+    __device__ __forceinline__ unsigned long long seed(unsigned img) const { return frame_seeds ? frame_seeds[img / V] : seed0; }
+    __device__ __forceinline__ unsigned image(unsigned img) const {
+        return frame_seeds ? frame_ids[img / V] * V + img % V : image0 + img;
+    }
+};
+
 // noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510), in two launches so that
 // the rare slow path (log / log-gamma acceptance test, further attempts) does not run
 // with 13 % of the lanes active on every wave:
@@ -65,7 +79,7 @@ __global__ void k_psf_dft_cols(const double2* __restrict__ s1, const double2* __
 // visits), fills it through an LDS counter and publishes the fill level in counts[].
 template <typename T>
 __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
-                               unsigned image0, unsigned long long seed, int rng_kind, unsigned* __restrict__ list,
+                               PoissonKeys keys, int rng_kind, unsigned* __restrict__ list,
                                unsigned seg_cap, unsigned* __restrict__ counts) {
     __shared__ unsigned fill;
     if (threadIdx.x == 0) fill = 0;
@@ -79,7 +93,8 @@ __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ 
             continue;
         }
         double k;
-        if (philox_poisson_fast(lam, seed, image0 + (unsigned)(i / n_pix), (unsigned)(i % n_pix), &k)) noisy[i] = (T)(k + 1e-9);
+        const unsigned img = (unsigned)(i / n_pix);
+        if (philox_poisson_fast(lam, keys.seed(img), keys.image(img), (unsigned)(i % n_pix), &k)) noisy[i] = (T)(k + 1e-9);
         else seg[atomicAdd(&fill, 1u)] = (unsigned)i;
     }
     __syncthreads();
@@ -87,14 +102,14 @@ __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ 
 }
 
 template <typename T>
-__global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned image0,
-                               unsigned long long seed, const unsigned* __restrict__ list, unsigned seg_cap,
+__global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, PoissonKeys keys, const unsigned* __restrict__ list, unsigned seg_cap,
                                const unsigned* __restrict__ counts) {
     const unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
     const unsigned n = counts[blockIdx.x];
     for (unsigned q = threadIdx.x; q < n; q += blockDim.x) {
         const unsigned i = seg[q];
-        noisy[i] = (T)(philox_poisson((double)noiseless[i], seed, image0 + i / n_pix, i % n_pix) + 1e-9);
+        const unsigned img = i / n_pix;
+        noisy[i] = (T)(philox_poisson((double)noiseless[i], keys.seed(img), keys.image(img), i % n_pix) + 1e-9);
     }
 }
 
@@ -157,7 +172,9 @@ hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev
 }
 
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
-                       unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s) {
+                       unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s,
+                       const unsigned long long* frame_seeds, const unsigned* frame_ids, unsigned V) {
+    const PoissonKeys keys{seed, image0, V ? V : 1u, frame_seeds, frame_ids};
     const size_t total = (size_t)n_pix * n_img;
     if (total >= 0xffffffffull) return hipErrorInvalidValue;      // 32-bit work-list entries
     const unsigned g = blocks_for(total, 256);
@@ -166,11 +183,11 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
     unsigned* list = (unsigned*)list_ws;
     unsigned* counts = list + (size_t)seg_cap * g;
     if (dtype == DT_F32) {
-        k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, image0, seed, rng_kind, list, seg_cap, counts);
-        if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, image0, seed, list, seg_cap, counts);
+        k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, keys, rng_kind, list, seg_cap, counts);
+        if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, keys, list, seg_cap, counts);
     } else {
-        k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, image0, seed, rng_kind, list, seg_cap, counts);
-        if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, image0, seed, list, seg_cap, counts);
+        k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, keys, rng_kind, list, seg_cap, counts);
+        if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, keys, list, seg_cap, counts);
     }
     return hipGetLastError();
 }

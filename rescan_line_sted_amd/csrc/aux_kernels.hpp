@@ -15,8 +15,11 @@ hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev
 // image0: index of the first image in the Philox counter (the draws of an image do not depend on
 // which slice of the batch a launch covers).
 size_t aux_poisson_workspace_bytes(size_t total_pixels);
+// frame_seeds / frame_ids (device arrays, one entry per frame of V views each) override seed / image0:
+// image (frame f, view v) then draws with seed frame_seeds[f] and image index frame_ids[f]*V + v.
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
-                       unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s);
+                       unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s,
+                       const unsigned long long* frame_seeds = nullptr, const unsigned* frame_ids = nullptr, unsigned V = 1);
 // float64 stack [frames][n] (device) -> plan dtype, each frame scaled to sum target[f]
 // (target / sums: device arrays of `frames` doubles; target == nullptr: no scaling)
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,

@@ -92,6 +92,7 @@ struct rl_deconv {
     hipEvent_t fork = nullptr;
     hipStream_t active = nullptr;                     // stream the kernel launch helpers use
     void* slice_ws = nullptr;                         // per-slice Poisson work lists of run_cycle()
+    void *key_seeds = nullptr, *key_ids = nullptr;    // per-frame Philox keys of rl_deconv_simulate_keyed
     size_t slice_ws_bytes = 0, slice_ws_stride = 0;
     hipStream_t cur() const { return active ? active : ctx->stream; }
     bool inplace = true;     // single-view RL iterations entirely in spec_a (RLSTED_INPLACE=0: spec_a -> spec_b -> spec_a)
@@ -437,7 +438,7 @@ int rl_deconv_destroy(rl_deconv* h) {
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
         if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
     void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
-                    h->stage_dev, h->stage_aux, h->slice_ws};
+                    h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -582,6 +583,28 @@ int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed) {
     HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 0, seed, rng_kind,
                         h->scratch, h->ctx->stream));
     HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    h->have_meas = true;
+    h->est_ready = false;
+    return RL_OK;
+}
+
+int rl_deconv_simulate_keyed(rl_deconv* h, int rng_kind, const uint64_t* seeds, const uint32_t* image_ids) {
+    if (!h || !seeds || !image_ids) return fail(RL_ERR_INVALID, "NULL argument");
+    if (!h->have_obj) return fail(RL_ERR_STATE, "rl_deconv_set_object has not been called");
+    if (rng_kind != RL_RNG_NONE && rng_kind != RL_RNG_PHILOX) return fail(RL_ERR_INVALID, "unknown rng_kind");
+    for (int f = 0; f < h->B; ++f)   // image index = id * V + view must fit the 32-bit Philox counter word
+        if ((uint64_t)image_ids[f] * (uint64_t)h->V + (uint64_t)h->V > 0xffffffffull) return fail(RL_ERR_INVALID, "image id too large");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    if (!h->key_seeds) {
+        HIP_TRY(hipMalloc(&h->key_seeds, (size_t)h->B * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&h->key_ids, (size_t)h->B * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMemcpyAsync(h->key_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h->key_ids, image_ids, (size_t)h->B * sizeof(uint32_t), hipMemcpyHostToDevice, h->ctx->stream));
+    HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 0, 0, rng_kind,
+                        h->scratch, h->ctx->stream, (const unsigned long long*)h->key_seeds, (const unsigned*)h->key_ids,
+                        (unsigned)h->V));
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));   // the host arrays may go away
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;

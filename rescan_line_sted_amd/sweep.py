@@ -4,9 +4,11 @@ script (line_sted_figure_2.py:29-57: one Deconvolver per PSF set and test image,
 create_data_from_object + N x iterate), batched and -- optionally -- sharded over
 GPUs with `sharding.run_sharded`.
 
-A task is (object name, PSF-set name, seed).  Tasks that share a PSF set, an image
-shape and a seed become the frames of one device plan (the frame index enters the
-Philox counter, so every frame still draws its own noise).
+A task is (object name, PSF-set name, seed).  All tasks that share a PSF set and an image
+shape become the frames of one device plan, whatever their seeds: a frame draws its noise with
+the Philox key (task seed, object id) -- `rl_deconv_simulate_keyed` -- where the object id is the
+position of the object's name in the sorted object names, so a task's result does not depend on
+how the sweep was batched or sharded.
 """
 import numpy as np
 
@@ -24,21 +26,27 @@ def task_costs(tasks, objects, psf_sets, iterations):
             for o, p, _ in tasks]
 
 
+def object_ids(objects):
+    """Stable image ids for the Philox counter: the rank of each object name."""
+    return {name: i for i, name in enumerate(sorted(objects))}
+
+
 def run_tasks(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype='f32', device=0,
               max_frames_per_plan=256):
     """Run tasks on one GPU.  Returns a list of (ny, nx) estimates in task order."""
     out = [None] * len(tasks)
+    ids = object_ids(objects)
     groups = {}
     for idx, (o, p, s) in enumerate(tasks):
         shape = objects[o].shape[-2:]
-        groups.setdefault((p, shape, s), []).append(idx)
-    for (p, shape, s), idxs in groups.items():
+        groups.setdefault((p, shape), []).append(idx)
+    for (p, shape), idxs in groups.items():
         for start in range(0, len(idxs), max_frames_per_plan):
             part = idxs[start:start + max_frames_per_plan]
             frames = np.stack([np.asarray(objects[tasks[i][0]], dtype=np.float64).reshape(shape) for i in part])
             plan = DeconvPlan(psf_sets[p], len(part), shape[0], shape[1], dtype=dtype, device=device)
             plan.set_object(frames, total_brightness)
-            plan.simulate(seed=s, rng=RNG_PHILOX)
+            plan.simulate_keyed([tasks[i][2] for i in part], [ids[tasks[i][0]] for i in part], rng=RNG_PHILOX)
             plan.iterate(iterations)
             est = plan.estimate()
             for k, i in enumerate(part):

@@ -161,8 +161,9 @@ def test_rotate_matches_reference_psf_sets(st, golden):
 
 
 def test_reduced_figure_2_sweep(golden):
-    """BASELINE config 4 in miniature: objects x PSF sets x seeds through sweep.py equals
-    the same frames run one plan at a time."""
+    """BASELINE config 4 in miniature: objects x PSF sets x seeds through sweep.py.  A task's
+    result depends on (object, PSF set, seed) only: running it alone in a plan of one frame, with
+    its own Philox key, reproduces the sweep's frame bit for bit, whatever it was batched with."""
     from rescan_line_sted_amd import sweep, _lib
     g8, objs = golden('g8_fig2_psfs'), golden('objects')
     objects = {n: objs[n][0].astype(np.float64) for n in ('astronaut', 'lines', 'rings')}
@@ -172,14 +173,41 @@ def test_reduced_figure_2_sweep(golden):
     assert len(tasks) == 12 and est.shape == (12, 128, 128)
     costs = sweep.task_costs(tasks, objects, psf_sets, 4)
     assert max(costs) == 3 * min(costs)                       # 3-view tasks weigh three point tasks
+    ids = sweep.object_ids(objects)
     for i in (0, 5, 11):
         o, p, s = tasks[i]
-        frames = [t for t in tasks if t[1] == p and t[2] == s]
-        plan = _lib.DeconvPlan(psf_sets[p], len(frames), 128, 128, dtype='f32')
-        plan.set_object(np.stack([objects[t[0]] for t in frames]), 5e10)
-        plan.simulate(seed=s)
+        plan = _lib.DeconvPlan(psf_sets[p], 1, 128, 128, dtype='f32')
+        plan.set_object(objects[o][None], 5e10)
+        plan.simulate_keyed([s], [ids[o]])
         plan.iterate(4)
-        assert np.array_equal(plan.estimate()[frames.index(tasks[i])], est[i])
+        assert np.array_equal(plan.estimate()[0], est[i])
+    # batched differently (one frame per plan): same results
+    alone = sweep.run_tasks(tasks[:5], objects, psf_sets, 4, max_frames_per_plan=1)
+    assert all(np.array_equal(a, e) for a, e in zip(alone, est[:5]))
+
+
+def test_keyed_simulate_equals_plain_simulate_and_the_oracle_twin(golden):
+    """seeds[f] = s, image_ids[f] = f is rl_deconv_simulate(s); arbitrary keys match the numpy
+    twin of the sampler called with the same (seed, image) per view."""
+    from rescan_line_sted_amd import _lib
+    from oracle import philox_poisson as pp
+    g8 = golden('g8_fig2_psfs')
+    psfs = [p[None] for p in g8['1p5x_lr/line_sted_psfs'][:, 0]]          # 3 views
+    rng = np.random.default_rng(2)
+    objs = rng.random((4, 40, 56)) * 3
+    plan = _lib.DeconvPlan(psfs, 4, 40, 56, dtype='f64')
+    plan.set_object(objs, [30.0 * 40 * 56, 8.0 * 40 * 56, 2e4 * 40 * 56, 0.5 * 40 * 56])   # below / above the PTRS switch at 10
+    plan.simulate(seed=77)
+    plain = plan.measurement()
+    plan.simulate_keyed([77] * 4, np.arange(4))
+    assert np.array_equal(plan.measurement(), plain)
+    seeds, ids = [5, 2 ** 40 + 3, 5, 9], [7, 0, 123456, 7]
+    plan.simulate_keyed(seeds, ids)
+    got, lam = plan.measurement(), plan.noiseless()
+    for f in range(4):
+        for v in range(3):
+            ref = pp.poisson(lam[f, v].ravel(), seeds[f], ids[f] * 3 + v).reshape(40, 56) + 1e-9
+            assert np.array_equal(got[f, v], ref), (f, v)
 
 
 # ------------------------------------------------ reconstruction quality (SURVEY 8 f-4, a-11)
