@@ -55,19 +55,32 @@ def run_tasks(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype
     return out
 
 
+def pad_stack(images, shape):
+    """Stack 2-D images of different sizes into one (n, shape[0], shape[1]) array, top-left aligned
+    and zero filled, so that one gather can carry them."""
+    out = np.zeros((len(images),) + tuple(shape), dtype=np.float64)
+    for k, im in enumerate(images):
+        out[k, :im.shape[0], :im.shape[1]] = im
+    return out
+
+
 def figure_2_sweep(objects, psf_sets, seeds, iterations, total_brightness=5e10, dtype='f32',
                    device=0, dist=None):
     """The sweep, sharded over the ranks of `dist` (an initialised torch.distributed
-    module) when given.  Objects must share one shape for the final gather.  Returns
-    (tasks, estimates[n_tasks, ny, nx]) on rank 0 and (tasks, None) elsewhere."""
+    module) when given.  Returns (tasks, estimates) on rank 0 and (tasks, None) elsewhere;
+    estimates is an array (n_tasks, ny, nx) when all objects share a shape, otherwise a list of
+    (ny, nx) arrays in task order (the figure's test objects are 128x128 and 160x160: the
+    single gather then carries frames zero-padded to the largest shape, cropped on rank 0)."""
     tasks = make_tasks(objects, psf_sets, seeds)
     costs = task_costs(tasks, objects, psf_sets, iterations)
+    shapes = {tuple(objects[o].shape[-2:]) for o, _, _ in tasks}
+    big = (max(s[0] for s in shapes), max(s[1] for s in shapes))
 
     def run_local(mine):
-        return np.stack(run_tasks(mine, objects, psf_sets, iterations, total_brightness, dtype, device))
-    if dist is None:
-        return tasks, run_local(tasks)
-    shapes = {tuple(objects[o].shape[-2:]) for o, _, _ in tasks}
-    if len(shapes) != 1:
-        raise ValueError('a sharded sweep gathers one stack: all objects must share a shape')
-    return tasks, sharding.run_sharded(tasks, costs, run_local, dist)
+        return pad_stack(run_tasks(mine, objects, psf_sets, iterations, total_brightness, dtype, device), big)
+    padded = sharding.run_sharded(tasks, costs, run_local, dist)
+    if padded is None:
+        return tasks, None
+    if len(shapes) == 1:
+        return tasks, padded
+    return tasks, [padded[i][:objects[o].shape[-2], :objects[o].shape[-1]] for i, (o, _, _) in enumerate(tasks)]
