@@ -245,6 +245,9 @@ struct rl_deconv {
         const double specs = (V == 1 && inplace) ? 1.0 : 1.0 + V;   // spectra alive in an iteration
         const double per_frame = (specs * 2.0 * n_spec() + (1.0 + V) * n_img()) * esize(dtype);
         int c = (int)(budget_mb * 1048576.0 / per_frame);
+        // many views: at least 8 frames per slice when no budget was given -- fewer leave the column
+        // kernels (37 workgroups per 512^2 frame) too small to fill the chip (6 / 8 views: +10 % / +7 %)
+        if (!getenv("RLSTED_CHUNK_MB") && c < 8 && per_frame * 8.0 <= 300.0 * 1048576.0) c = 8;
         if (c < 1) c = 1;
         if (c >= B) return B;
         // equal slices (a short last slice would run its 4 launches per iteration nearly empty)
