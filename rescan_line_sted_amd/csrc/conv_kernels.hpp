@@ -143,7 +143,7 @@ enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2 };
 template <class Cfg, int C, int MODE, typename T, class Sync>
 RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
-    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
+    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     constexpr int NT = 64 * C;
     static_assert((L * C) % NT == 0, "tile must divide evenly over the workgroup");
@@ -155,7 +155,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     const int col0 = bx * C, col = col0 + w;
     const bool colok = col < p.kx;
     const size_t img = (size_t)p.ny * p.pitch;
-    LdsView<T, 1> view_lds{lds + w * LP};
+    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
 
     // tile element e = tid + it*NT  <->  (row = e / C, column c = e % C)
     auto load_tile = [&](const cx<T>* __restrict__ in) {
@@ -170,7 +170,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
-            lds[(e % C) * LP + lds_pad(e / C)] = x[it];
+            lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
         }
     };
     auto store_tile = [&](cx<T>* __restrict__ out) {
@@ -178,7 +178,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
             const int row = e / C, c = e % C;
-            if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+            if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + view_lds.nat(row)];
         }
     };
     // v, tl *= psf_hat[view] column (register layout of the last forward pass)
@@ -204,7 +204,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
             const int j = lane + nb * 64;
             if (j < IL::NBF) {
 #pragma unroll
-                for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, lds_pad(j), r) = v[nb * IL::R + r];
+                for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
             }
         }
     };
@@ -322,7 +322,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     const int r0 = 2 * (bx * Q + q), r1 = r0 + 1;
     const bool ok0 = r0 < p.ny, ok1 = r1 < p.ny;
     const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
-    LdsView<T, 1> view_lds{lds + q * LdsLen<L>::value};
+    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + q * LdsSlots<Cfg>::value};
 
     // element index held in register slot (nb, r) after an inverse / before a forward
     using IL = PassInfo<Cfg, true, NP - 1>;
@@ -490,7 +490,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             const int j = t + nb * TT;
             if (j < FL::NBF) {
 #pragma unroll
-                for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, lds_pad(j), r) = v[nb * FL::R + r];
+                for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, view_lds.nat(j), r) = v[nb * FL::R + r];
             }
         }
         fft_sync<Cfg>(sync);
@@ -565,7 +565,7 @@ struct StreamOrder {
 template <class Cfg, int C, typename T, class Sync>
 RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
-    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsLen<L>::value;
+    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     constexpr int NT = 64 * C;
     static_assert((L * C) % NT == 0, "tile must divide evenly over the workgroup");
@@ -575,7 +575,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
     static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
     const int w = tid / 64, lane = tid % 64;
     const size_t img = (size_t)p.ny * p.pitch;
-    LdsView<T, 1> view_lds{lds + w * LP};
+    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
 
     for (int i = tid; i < StreamTw<Cfg>::COUNT; i += NT) lds[C * LP + i] = p.tw[i];
 
@@ -605,7 +605,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
     for (int k = 0; lin >= 0; ++k) {
         const cx<T>* tw = lds + stream_launder(C * LP);
         const int tid = stream_launder_lane(tid0), w = tid / 64, lane = tid % 64;
-        LdsView<T, 1> view_lds{lds + w * LP};
+        LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
         const int by = lin / tiles, col0 = (lin % tiles) * C, col = col0 + w;
         const bool colok = col < p.kx;
         const int view = by % p.V;
@@ -614,7 +614,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
             const bool ok = e / C < p.ny && col0 + e % C < p.kx;
-            lds[(e % C) * LP + lds_pad(e / C)] = mk<T>(ok ? x[it].re : (T)0, ok ? x[it].im : (T)0);
+            lds[(e % C) * LP + view_lds.nat(e / C)] = mk<T>(ok ? x[it].re : (T)0, ok ? x[it].im : (T)0);
         }
         rl_stamp(sync, 1);
         sync.wg();
@@ -646,7 +646,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
                 const int j = lane + nb * 64;
                 if (j < IL::NBF) {
 #pragma unroll
-                    for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, lds_pad(j), r) = v[nb * IL::R + r];
+                    for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
                 }
             }
         } else {
@@ -661,7 +661,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
             for (int it = 0; it < NLD; ++it) {
                 const int e = tid + it * NT;
                 const int row = e / C, c = e % C;
-                if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + lds_pad(row)];
+                if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + view_lds.nat(row)];
             }
         }
         rl_stamp(sync, 7);
@@ -709,8 +709,8 @@ struct RowSpectra {
 // row (wave uniform); t: lane; tl_: lane index used for LDS addressing; tw: twiddle table (global
 // memory or LDS); `after_pack` runs once `in` has been consumed (the streaming body requests the
 // next item's spectra there).
-template <class Cfg, int MODE, bool NRM_EARLY, typename T, class Sync, class AfterPack>
-RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, RowSpectra<Cfg, T>& in, LdsView<T, 1> view_lds,
+template <class Cfg, int MODE, bool NRM_EARLY, typename T, class View, class Sync, class AfterPack>
+RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, RowSpectra<Cfg, T>& in, View view_lds,
                     const cx<T>* tw, Sync& sync, AfterPack&& after_pack) {
     static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "RL modes only");
     constexpr int NP = Cfg::NP, L = Cfg::L;
@@ -804,7 +804,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
         const int j = tl_ + nb * 64;
         if (j < FL::NBF) {
 #pragma unroll
-            for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, lds_pad(j), r) = v[nb * FL::R + r];
+            for (int r = 0; r < FL::R; ++r) view_lds.template at_step<FL::NBF>(j, view_lds.nat(j), r) = v[nb * FL::R + r];
         }
     }
     fft_sync<Cfg>(sync);
@@ -825,11 +825,11 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
-    constexpr int LP = LdsLen<Cfg::L>::value;
+    constexpr int LP = LdsSlots<Cfg>::value;
     static_assert((size_t)Cfg::L * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");   // overrun < L elements
     const int q = rl_uniform(tid / 64);
     const unsigned t = (unsigned)(tid % 64);
-    LdsView<T, 1> view_lds{lds + q * LP};
+    LdsView<T, 1, LdsGather<Cfg::L>::value> view_lds{lds + q * LP};
 
     for (int i = tid; i < StreamTw<Cfg>::COUNT; i += 64 * Q) lds[Q * LP + i] = p.tw[i];
 
@@ -857,14 +857,14 @@ RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "lean row body needs wave-private transforms");
-    constexpr int LP = LdsLen<Cfg::L>::value;
+    constexpr int LP = LdsSlots<Cfg>::value;
     const int q = rl_uniform(tid / 64);
     const unsigned t = (unsigned)(tid % 64);
     const int r0 = 2 * (bx * Q + q);
     if (r0 >= p.ny) return;   // whole wave; the wave-private row kernels have no workgroup barrier
     RowSpectra<Cfg, T> in;
     in.request(p, by, r0, t);
-    row_item<Cfg, MODE, RL_LEAN_NRM_EARLY != 0>(p, t, (int)t, by, r0, in, LdsView<T, 1>{lds + q * LP}, p.tw, sync, [] {});
+    row_item<Cfg, MODE, RL_LEAN_NRM_EARLY != 0>(p, t, (int)t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync, [] {});
 }
 
 }  // namespace rl

@@ -60,6 +60,20 @@ struct CfgFor<4608> { // 4096 + 53: one transform per workgroup (functional supp
     static constexpr int C32 = 1, C64 = 1, Q32 = 1, Q64 = 1;
 };
 
+// LDS layout per length: the gathered exchange layout (fft_core.hpp, LdsGather) for the
+// wave-private geometries
+#ifndef RL_LDS_GATHER
+#define RL_LDS_GATHER 1
+#endif
+template <>
+struct LdsGather<256> {
+    static constexpr bool value = RL_LDS_GATHER != 0;
+};
+template <>
+struct LdsGather<576> {
+    static constexpr bool value = RL_LDS_GATHER != 0;
+};
+
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads
 template <int L>
 constexpr bool cfg_fits() {

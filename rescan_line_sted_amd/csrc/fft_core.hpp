@@ -195,19 +195,37 @@ struct LdsLen {
     static constexpr int value = L + (L >> 3) + 1;
 };
 
+// Which LDS layout a transform length uses.  false: natural order with one pad slot per 8
+// (above).  true (set in fft_configs.hpp for the wave-private lengths): the "gathered" layout --
+// natural order is stored unpadded, and an inter-pass exchange stores register slot r of
+// butterfly j at r*S + j (contiguous across the lanes: the 6-cycle ds_write_b64 never conflicts)
+// while the next pass gathers its operands with a per-lane base and a constant step per register.
+// S is chosen per exchange so that the 32 lanes of a ds_read_b64 group fall on 32 different
+// 8-byte bank pairs (Exchange::pick).  Under `idx + idx/8` every stride-1 read window spans a pad
+// slot and takes 3 LDS cycles instead of 2 (46 % of the LDS cycles were bank conflicts).
+template <int L>
+struct LdsGather {
+    static constexpr bool value = false;
+};
+
 // View of one transform's LDS storage.  CS = element stride (1 for the row
 // kernels' [fft][idx] layout, C for the column kernels' [idx][column] layout).
-template <typename T, int CS>
+// G: gathered layout (natural order unpadded).
+template <typename T, int CS, bool G = false>
 struct LdsView {
+    static constexpr bool gathered = G;
     cx<T>* base;
-    RL_HD cx<T>& at(int idx) const { return base[lds_pad(idx) * CS]; }
+    RL_HD static int nat(int idx) { return G ? idx : lds_pad(idx); }   // slot of natural-order element idx
+    RL_HD cx<T>& at(int idx) const { return base[nat(idx) * CS]; }
+    RL_HD cx<T>& slot(int s) const { return base[s * CS]; }
     // Element idx0 + k*STEP, with the padded position of idx0 already known.  For a step that
     // is a multiple of 8 the padding is linear, lds_pad(idx0 + k*STEP) = lds_pad(idx0) +
     // k*(STEP + STEP/8): one lane address plus a compile-time offset that folds into the
     // immediate field of the ds_read / ds_write, instead of shift + add per access.
     template <int STEP>
     RL_HD cx<T>& at_step(int idx0, int pad0, int k) const {
-        if constexpr (STEP % 8 == 0) return base[(pad0 + k * (STEP + STEP / 8)) * CS];
+        if constexpr (G) return base[(idx0 + k * STEP) * CS];
+        else if constexpr (STEP % 8 == 0) return base[(pad0 + k * (STEP + STEP / 8)) * CS];
         else return base[lds_pad(idx0 + k * STEP) * CS];
     }
 };
@@ -284,37 +302,112 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
     }
 }
 
-template <class Cfg, bool INV, int P, typename T, int CS>
-RL_HD void pass_store_lds(const cx<T>* v, int t, LdsView<T, CS> lds) {
+// Gathered layout of the exchange between pass P (producer) and pass P + 1 (consumer).
+// Producer: slot(r, j) = r*S + j.  Consumer register r' of butterfly j' is transform element
+// idx = j' + r'*NBF'; the producer butterfly that wrote it is j = (idx/(NS R)) NS + idx % NS with
+// output r = (idx/NS) % R, and since NS R divides NBF' both split into a part that depends on j'
+// only and a constant step per r':  slot = base(j') + r' * STEP.
+template <class Cfg, bool INV, int P>
+struct Exchange {
+    using PI = PassInfo<Cfg, INV, P>;
+    using PN = PassInfo<Cfg, INV, P + 1>;
+    static constexpr int R = PI::R, NS = PI::NS, NBF = PI::NBF;
+    static constexpr int STEP = (Cfg::L / (NS * R * PN::R)) * NS;
+    static constexpr int base_(int jn, int S) { return ((jn / NS) % R) * S + (jn / (NS * R)) * NS + jn % NS; }
+    // extra LDS cycles of one consumer read under stride S: lanes 0-31 and 32-63 are serviced
+    // separately, each over 32 bank pairs (8 bytes per lane)
+    static constexpr int conflicts(int S) {
+        int extra = 0;
+        for (int g = 0; g < 2; ++g) {
+            int cnt[32] = {};
+            int worst = 0;
+            for (int l = 32 * g; l < 32 * g + 32 && l < PN::NBF; ++l) {
+                const int c = ++cnt[base_(l, S) % 32];
+                if (c > worst) worst = c;
+            }
+            extra += worst > 1 ? worst - 1 : 0;
+        }
+        return extra;
+    }
+    static constexpr int pick() {
+        int best = NBF, bc = conflicts(NBF);
+        for (int S = NBF + 1; S <= NBF + 32 && bc > 0; ++S)
+            if (conflicts(S) < bc) { best = S; bc = conflicts(S); }
+        return best;
+    }
+    static constexpr int S = pick();
+    static constexpr int SLOTS = R * S;
+    RL_HD static int consumer_base(int jn) { return base_(jn, S); }
+};
+
+// LDS slots of one transform: the padded natural order, or -- gathered -- the largest exchange
+// (and the unpadded natural order), rounded up to 2 mod 16 so that the 8 columns a 16-lane
+// ds_write_b64 group of the column kernel's tile load touches fall on different bank pairs.
+template <class Cfg, bool INV, int P>
+constexpr int exchange_slots_from() {
+    if constexpr (P + 1 < Cfg::NP) {
+        constexpr int a = Exchange<Cfg, INV, P>::SLOTS, b = exchange_slots_from<Cfg, INV, P + 1>();
+        return a > b ? a : b;
+    } else {
+        return 0;
+    }
+}
+template <class Cfg>
+struct LdsSlots {
+    static constexpr int gathered_() {
+        int m = Cfg::L;
+        const int a = exchange_slots_from<Cfg, false, 0>(), b = exchange_slots_from<Cfg, true, 0>();
+        if (a > m) m = a;
+        if (b > m) m = b;
+        return (m + 13) / 16 * 16 + 2;
+    }
+    static constexpr int value = LdsGather<Cfg::L>::value ? gathered_() : LdsLen<Cfg::L>::value;
+};
+
+template <class Cfg, bool INV, int P, typename T, class View>
+RL_HD void pass_store_lds(const cx<T>* v, int t, View lds) {
     using PI = PassInfo<Cfg, INV, P>;
     constexpr int R = PI::R;
 #pragma unroll
     for (int nb = 0; nb < PI::NBM; ++nb) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
-            const int j0 = (j / PI::NS) * (PI::NS * R) + (j % PI::NS);
-            // NS == 1, R == 8: lds_pad(8j + r) = 9j + r
-            const int p0 = (PI::NS == 1 && R == 8) ? 9 * j : lds_pad(j0);
+            if constexpr (View::gathered) {
+                using X = Exchange<Cfg, INV, P>;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if constexpr (PI::NS == 1 && R == 8) lds.base[(p0 + r) * CS] = v[nb * R + r];
-                else lds.template at_step<PI::NS>(j0, p0, r) = v[nb * R + r];
+                for (int r = 0; r < R; ++r) lds.slot(j + r * X::S) = v[nb * R + r];
+            } else {
+                const int j0 = (j / PI::NS) * (PI::NS * R) + (j % PI::NS);
+                // NS == 1, R == 8: lds_pad(8j + r) = 9j + r
+                const int p0 = (PI::NS == 1 && R == 8) ? 9 * j : lds_pad(j0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if constexpr (PI::NS == 1 && R == 8) lds.slot(p0 + r) = v[nb * R + r];
+                    else lds.template at_step<PI::NS>(j0, p0, r) = v[nb * R + r];
+                }
             }
         }
     }
 }
 
-template <class Cfg, bool INV, int P, typename T, int CS>
-RL_HD void pass_load_lds(cx<T>* v, int t, LdsView<T, CS> lds) {
+template <class Cfg, bool INV, int P, typename T, class View>
+RL_HD void pass_load_lds(cx<T>* v, int t, View lds) {
     using PI = PassInfo<Cfg, INV, P>;
     constexpr int R = PI::R;
 #pragma unroll
     for (int nb = 0; nb < PI::NBM; ++nb) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
-            const int p0 = lds_pad(j);
+            if constexpr (View::gathered && P > 0) {
+                using X = Exchange<Cfg, INV, (P > 0 ? P - 1 : 0)>;
+                const int b = X::consumer_base(j);
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[nb * R + r] = lds.template at_step<PI::NBF>(j, p0, r);
+                for (int r = 0; r < R; ++r) v[nb * R + r] = lds.slot(b + r * X::STEP);
+            } else {   // natural order (first pass, or the padded layout)
+                const int p0 = View::nat(j);
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[nb * R + r] = lds.template at_step<PI::NBF>(j, p0, r);
+            }
         }
     }
 }
@@ -425,14 +518,19 @@ RL_HD int tail_out_index(int lane, int k) {   // Stockham scatter position of ou
 // One TAIL pass for the tail element: [load] -> inter-pass twiddle -> cross-lane DFT.
 // FROM_REGS (only the chained inverse first pass): tl arrives in bit-reversed order
 // from the previous forward tail and the DIT network is used (NS == 1, no twiddle).
-template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, int CS, class Sync>
-RL_HD void tail_compute(cx<T>& tl, int lane, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
+template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, class View, class Sync>
+RL_HD void tail_compute(cx<T>& tl, int lane, View lds, const cx<T>* __restrict__ tw, Sync& sync) {
     using PI = PassInfo<Cfg, INV, P>;
     if constexpr (FROM_REGS) {
         static_assert(PI::NS == 1, "a register-chained tail must be the first pass");
         tl = tail_dft8<INV, true>(tl, lane, sync);
     } else {
-        tl = lds.at(tail_in_index<Cfg, INV, P>(lane));
+        if constexpr (View::gathered && P > 0) {   // consumer element j' = 64 + jj, register r' = lane >> 3
+            using X = Exchange<Cfg, INV, (P > 0 ? P - 1 : 0)>;
+            tl = lds.slot(X::consumer_base(64 + (lane & 7)) + (lane >> 3) * X::STEP);
+        } else {
+            tl = lds.at(tail_in_index<Cfg, INV, P>(lane));
+        }
         if constexpr (PI::NS > 1) {
             const int r = lane >> 3, j = 64 + (lane & 7);
             if (r > 0) tl = cmul(tl, tw[PassTw<Cfg, INV, P>::OFFSET + (r - 1) * PI::NBF + j]);
@@ -447,8 +545,8 @@ RL_HD void tail_compute(cx<T>& tl, int lane, LdsView<T, CS> lds, const cx<T>* __
 // a TAIL pass additionally `tl` <-> element tail index (64+jj) + 72*bitrev3(p).
 // Every LDS scatter is bracketed by syncs (all threads of the transform --
 // the whole workgroup unless the transform is wave private -- must call this).
-template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, int CS, class Sync>
-RL_HD void run_passes(cx<T>* v, cx<T>& tl, int t, LdsView<T, CS> lds, const cx<T>* __restrict__ tw, Sync& sync) {
+template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, class View, class Sync>
+RL_HD void run_passes(cx<T>* v, cx<T>& tl, int t, View lds, const cx<T>* __restrict__ tw, Sync& sync) {
     using PI = PassInfo<Cfg, INV, P>;
     if constexpr (!FROM_REGS) pass_load_lds<Cfg, INV, P>(v, t, lds);
     if constexpr (PI::TAIL) tail_compute<Cfg, INV, P, FROM_REGS>(tl, t, lds, tw, sync);
@@ -458,7 +556,8 @@ RL_HD void run_passes(cx<T>* v, cx<T>& tl, int t, LdsView<T, CS> lds, const cx<T
         pass_store_lds<Cfg, INV, P>(v, t, lds);
         if constexpr (PI::TAIL) {
             const int k = FROM_REGS ? (t >> 3) : bitrev3(t >> 3);   // DIT leaves natural order, DIF bit-reversed
-            lds.at(tail_out_index<Cfg, INV, P>(t, k)) = tl;
+            if constexpr (View::gathered) lds.slot(k * Exchange<Cfg, INV, P>::S + 64 + (t & 7)) = tl;   // output k of butterfly 64 + jj
+            else lds.at(tail_out_index<Cfg, INV, P>(t, k)) = tl;
         }
         fft_sync<Cfg>(sync);
         run_passes<Cfg, INV, P + 1, false>(v, tl, t, lds, tw, sync);

@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64 * Q, sizeof(T) == 4 ? RL_STREAM_ROW_MIN_WAV
 
 template <int N, typename T>
 static constexpr size_t stream_lds_bytes() {
-    return ((size_t)N * LdsLen<Cfg::L>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>);
+    return ((size_t)N * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>);
 }
 
 // workgroups of `fn` that the device holds at once (0 on error), a multiple of 8 (one share per XCD)
@@ -201,7 +201,7 @@ static hipError_t launch_row_stream(int dtype, int mode, const void* params, hip
 
 template <int C, typename T>
 static constexpr size_t lds_bytes() {
-    return (size_t)C * LdsLen<Cfg::L>::value * sizeof(cx<T>);
+    return (size_t)C * LdsSlots<Cfg>::value * sizeof(cx<T>);
 }
 
 template <int C, typename T>

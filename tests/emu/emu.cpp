@@ -99,14 +99,14 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     if constexpr (WavePrivate<Cfg>::value) {
         if (g_stream_nwg > 0 && mode == COL_PER_IMAGE) {
             const int nwg = g_stream_nwg;
-            run_grid(nwg, 1, 64 * C, ((size_t)C * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
+            run_grid(nwg, 1, 64 * C, ((size_t)C * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
                      [&](int tid, int bx, int, unsigned char* lds, EmuSync& s) {
                          colstream_body<Cfg, C, T>(p, tid, bx, nwg, reinterpret_cast<cx<T>*>(lds), s);
                      });
             return 0;
         }
     }
-    run_grid((kx + C - 1) / C, gy, Cfg::T * C, (size_t)C * LdsLen<L>::value * sizeof(cx<T>),
+    run_grid((kx + C - 1) / C, gy, Cfg::T * C, (size_t)C * LdsSlots<Cfg>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  if constexpr (WavePrivate<Cfg>::value)
                      switch (mode) {   // same dispatch as launch_col_t in fft_kernels.hip
@@ -132,14 +132,14 @@ static int row_m(const RowParams<T>& p, int gy) {
             const int nwg = g_stream_nwg;
             RowParams<T> ps = p;
             ps.frames = gy;
-            run_grid(nwg, 1, 64 * QS, ((size_t)QS * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
+            run_grid(nwg, 1, 64 * QS, ((size_t)QS * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
                      [&](int tid, int bx, int, unsigned char* lds, EmuSync& s) {
                          rowstream_body<Cfg, QS, MODE, T>(ps, tid, bx, nwg, reinterpret_cast<cx<T>*>(lds), s);
                      });
             return 0;
         }
     }
-    run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsLen<L>::value * sizeof(cx<T>),
+    run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
                  if constexpr (WavePrivate<Cfg>::value && (MODE == ROW_RATIO || MODE == ROW_UPDATE)) {

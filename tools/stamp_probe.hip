@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
     RowParams<float> rp;
     rp.spec_in = (const cx<float>*)spec_b; rp.spec_out = (cx<float>*)spec_a; rp.src = meas; rp.dst = est; rp.norm = norm;
     rp.scale = nullptr; rp.tw = (const cx<float>*)tw; rp.ny = ny; rp.nx = nx; rp.pitch = pitch; rp.V = 1;
-    const size_t ldc = (size_t)C * LdsLen<L>::value * 8, ldr = (size_t)Q * LdsLen<L>::value * 8;
+    const size_t ldc = (size_t)C * LdsSlots<Cfg>::value * 8, ldr = (size_t)Q * LdsSlots<Cfg>::value * 8;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     auto timeit = [&](auto launch, const char* name, size_t waves, int ns) {
@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
     // streaming kernels: the stamps of each wave's LAST item survive
     cp.images = B; rp.frames = B;
     constexpr int QS = PROBE_QS;
-    const size_t ldcs = ((size_t)C * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * 8, ldrs = ((size_t)QS * LdsLen<L>::value + StreamTw<Cfg>::COUNT) * 8;
+    const size_t ldcs = ((size_t)C * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * 8, ldrs = ((size_t)QS * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * 8;
     auto plain = [&](auto launch, const char* name) {
         float ms = 0, best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
