@@ -166,7 +166,10 @@ def main():
         'rowpass_UPDATE': (K_ITERS, V * spec + 3 * img + spec),
     }
     per_cycle_ms = {k: kt[k] * launches[k][0] for k in launches}
-    dom = max(per_cycle_ms, key=per_cycle_ms.get)
+    # the two column launches of an iteration are one kernel (k_colconv): judged together
+    kernel_ms = {'colconv': per_cycle_ms['colconv_H'] + per_cycle_ms['colconv_Ht'],
+                 'rowpass_RATIO': per_cycle_ms['rowpass_RATIO'], 'rowpass_UPDATE': per_cycle_ms['rowpass_UPDATE']}
+    dom = max(kernel_ms, key=kernel_ms.get)
     iter_ms = kt['colconv_H'] + kt['rowpass_RATIO'] + kt['colconv_Ht'] + kt['rowpass_UPDATE']
     alg_iter = 4 * n_pix * (3 * V + 4) * FL     # algorithmic bytes of one RL iteration over one slice
     # the dominant kernel's share of the iteration's algorithmic bytes: pass 1
@@ -176,7 +179,9 @@ def main():
     # pass's bytes as well, i.e. achieved = pass bytes / (pass's two launches).
     pass1 = 4 * n_pix * (2 * V + 1) * FL
     pass2 = 4 * n_pix * (V + 3) * FL
-    if dom in ('colconv_H', 'rowpass_RATIO'):
+    if dom == 'colconv':      # one launch in each pass: half the iteration's bytes per launch pair, on average
+        pass_bytes, pass_ms = alg_iter / 2, iter_ms / 2
+    elif dom == 'rowpass_RATIO':
         pass_bytes, pass_ms = pass1, kt['colconv_H'] + kt['rowpass_RATIO']
     else:
         pass_bytes, pass_ms = pass2, kt['colconv_Ht'] + kt['rowpass_UPDATE']
@@ -189,7 +194,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
         if (pmc.get('frames_per_launch') == FL and pmc.get('dtype') == args.dtype and pmc.get('n_psf') == V
                 and pmc.get('shape') == [NY, NX] and dom in pmc):
-            traffic = pmc[dom]['hbm_bytes_per_launch']
+            traffic = pmc[dom]['hbm_bytes_per_launch']      # 'colconv': the same for the H and the H_t launch
     except (OSError, ValueError):
         pass
     roofline = {
