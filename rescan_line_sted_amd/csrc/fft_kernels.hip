@@ -48,18 +48,30 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && WaveP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
-    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs, so
-    // linear ids l and l+8 share an L2.  Two adjacent column tiles share every
-    // 128-B line of the spectrum rows (64 B each); giving each XCD a contiguous
-    // range of (image, tile) work items puts them on the same L2 at about the same
-    // time.  Pure speed heuristic -- any placement is correct.
+    // XCD-aware work order (pure speed heuristic -- any placement is correct).  Workgroups are dealt
+    // round-robin over the 8 XCDs, so linear ids l and l+8 share an L2; every XCD gets a contiguous
+    // range of the item sequence.  Image-major (p.order == 0, default): tile after tile of one image,
+    // then the next image -- the two tiles that share every 128-B line of the spectrum rows (64 B
+    // each) are neighbours.  Tile-major (p.order == 1): for tile pair, for image, for the two tiles
+    // of the pair -- additionally keeps the psf_hat columns of an XCD's few tiles in its L2
+    // (image-major streams the whole 1.33 MB psf_hat through every XCD once per image).
     unsigned bx = blockIdx.x, by = blockIdx.y;
-    const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
     if (total % 8 == 0) {
         const unsigned lin = by * gx + bx;
         const unsigned w = (lin % 8) * (total / 8) + lin / 8;
-        bx = w % gx;
-        by = w / gx;
+        const unsigned paired = (gx & ~1u) * gy;          // items that belong to full tile pairs
+        if (p.order == 0) {
+            bx = w % gx;
+            by = w / gx;
+        } else if (w < paired) {
+            const unsigned pr = w / (2 * gy), q = w % (2 * gy);
+            bx = 2 * pr + (q & 1u);
+            by = q >> 1;
+        } else {
+            bx = gx - 1;
+            by = w - paired;
+        }
     }
     if constexpr (WavePrivate<KCfg>::value)
         colconv_wave_body<KCfg, C, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
