@@ -36,6 +36,35 @@ RL_HD float rl_div(float a, float b) {
 }
 RL_HD double rl_div(double a, double b) { return a / b; }
 
+// ---------------------------------------------------------------------------
+// Layout of a row-transformed spectrum image in global memory (ny rows x pitch columns of
+// complex T, pitch a multiple of 8): plain row-major rows, or -- RL_SPEC_BLOCKED -- blocked as
+// [row pair][8-column block][row parity][8 columns], so that the 2 x 8 elements two consecutive
+// rows contribute to an 8-column tile are one contiguous 128-byte line (f32) and every line a
+// column tile touches is its own (the row kernels work on row pairs and then read / write both
+// halves of the same lines back to back).  Built, tested (emulator and GPU) and measured: the
+// column kernel's fabric reads do not change (1.90 MB per frame either way -- its excess over the
+// 1.21 MB spectrum is psf_hat being re-fetched, not half-used lines) and the path is 1.1 % slower
+// (same-box A/B), so row-major stays the default.
+#ifndef RL_SPEC_BLOCKED
+#define RL_SPEC_BLOCKED 0
+#endif
+RL_HD int spec_rows(int ny) { return RL_SPEC_BLOCKED ? (ny + 1) & ~1 : ny; }
+RL_HD size_t spec_image_elems(int ny, int pitch) { return (size_t)spec_rows(ny) * pitch; }
+RL_HD size_t spec_off(int row, int col, int pitch) {
+#if RL_SPEC_BLOCKED
+    return ((size_t)(row >> 1) * (pitch >> 3) + (col >> 3)) * 16 + ((row & 1) << 3) + (col & 7);
+#else
+    return (size_t)row * pitch + col;
+#endif
+}
+// element offset of column k relative to the start of a row pair's storage (row parity 0):
+// lanes t + 64 it use  spec_pair_lane(t) + it * SPEC_PAIR_STEP64; the odd row is SPEC_ODD_ROW further
+RL_HD size_t spec_pair_off(int pair, int pitch) { return (size_t)pair * 2 * pitch; }
+RL_HD unsigned spec_pair_col(unsigned k) { return RL_SPEC_BLOCKED ? 2 * k - (k & 7) : k; }
+constexpr unsigned SPEC_PAIR_STEP64 = RL_SPEC_BLOCKED ? 128 : 64;   // 64 columns further
+RL_HD unsigned spec_odd_row(int pitch) { return RL_SPEC_BLOCKED ? 8u : (unsigned)pitch; }
+
 // ------------------------------ column pass --------------------------------
 // For one tile of C spectrum columns: forward FFT along y (rows >= ny are
 // zero), multiply by psf_hat, inverse FFT along y, keep rows < ny.
@@ -69,7 +98,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
     const int col = bx * C + c;
     const bool colok = col < p.kx;
     const int frame = by / p.V, view = by % p.V;
-    const size_t img = (size_t)p.ny * p.pitch;
+    const size_t img = spec_image_elems(p.ny, p.pitch);
     const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
     cx<T>* __restrict__ out = p.out + (size_t)by * img;
     const cx<T>* __restrict__ ph = p.psf_hat + (size_t)view * Cfg::L * p.pitch;
@@ -86,7 +115,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
             for (int r = 0; r < F0::R; ++r) {
                 const int i = j + r * F0::NBF;
                 cx<T> x = mk<T>((T)0, (T)0);
-                if (j < F0::NBF && colok && i < p.ny) x = in[(size_t)i * p.pitch + col];
+                if (j < F0::NBF && colok && i < p.ny) x = in[spec_off(i, col, p.pitch)];
                 v[nb * F0::R + r] = x;
             }
         }
@@ -113,7 +142,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
 #pragma unroll
             for (int r = 0; r < IL::R; ++r) {
                 const int i = j + r * IL::NBF;
-                if (j < IL::NBF && colok && i < p.ny) out[(size_t)i * p.pitch + col] = v[nb * IL::R + r];
+                if (j < IL::NBF && colok && i < p.ny) out[spec_off(i, col, p.pitch)] = v[nb * IL::R + r];
             }
         }
     }
@@ -155,7 +184,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     const int w = tid / 64, lane = tid % 64;
     const int col0 = bx * C, col = col0 + w;
     const bool colok = col < p.kx;
-    const size_t img = (size_t)p.ny * p.pitch;
+    const size_t img = spec_image_elems(p.ny, p.pitch);
     LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
 
     // tile element e = tid + it*NT  <->  (row = e / C, column c = e % C)
@@ -166,7 +195,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
             const int e = tid + it * NT;
             const int row = e / C, c = e % C;
             x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx) x[it] = in[(size_t)row * p.pitch + col0 + c];
+            if (row < p.ny && col0 + c < p.kx) x[it] = in[spec_off(row, col0 + c, p.pitch)];
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -179,7 +208,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
             const int row = e / C, c = e % C;
-            if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + view_lds.nat(row)];
+            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP + view_lds.nat(row)];
         }
     };
     // v, tl *= psf_hat[view] column (register layout of the last forward pass)
@@ -322,7 +351,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     const int q = tid / TT, t = tid % TT;
     const int r0 = 2 * (bx * Q + q), r1 = r0 + 1;
     const bool ok0 = r0 < p.ny, ok1 = r1 < p.ny;
-    const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
+    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
     LdsView<T, 1, LdsGather<L>::value> view_lds{lds + q * LdsSlots<Cfg>::value};
 
     // element index held in register slot (nb, r) after an inverse / before a forward
@@ -379,8 +408,8 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 const int k = t + it * TT;
                 A[it] = mk<T>((T)0, (T)0);
                 B[it] = mk<T>((T)0, (T)0);
-                if (k <= L / 2 && ok0) A[it] = sp[(size_t)r0 * p.pitch + k];
-                if (k <= L / 2 && ok1) B[it] = sp[(size_t)r1 * p.pitch + k];
+                if (k <= L / 2 && ok0) A[it] = sp[spec_off(r0, k, p.pitch)];
+                if (k <= L / 2 && ok1) B[it] = sp[spec_off(r1, k, p.pitch)];
             }
 #pragma unroll
             for (int it = 0; it < NPK; ++it) {
@@ -502,8 +531,8 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             const int k = t + it * TT;
             if (k <= L / 2) {
                 const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
-                if (ok0) so[(size_t)r0 * p.pitch + k] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
-                if (ok1) so[(size_t)r1 * p.pitch + k] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+                if (ok0) so[spec_off(r0, k, p.pitch)] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
+                if (ok1) so[spec_off(r1, k, p.pitch)] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
             }
         }
         rl_stamp(sync, 5);
@@ -575,7 +604,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
     using IL = PassInfo<Cfg, true, NP - 1>;
     static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
     const int w = tid / 64, lane = tid % 64;
-    const size_t img = (size_t)p.ny * p.pitch;
+    const size_t img = spec_image_elems(p.ny, p.pitch);
     LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
 
     for (int i = tid; i < StreamTw<Cfg>::COUNT; i += NT) lds[C * LP + i] = p.tw[i];
@@ -596,7 +625,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
             const int e = tid + it * NT;
             const int row = e / C, c = e % C;
             const int rr = row < p.ny ? row : p.ny - 1, cc = col0 + c < p.pitch ? col0 + c : p.pitch - 1;
-            x[it] = in[(size_t)rr * p.pitch + cc];   // zero selected where it is consumed, not here:
+            x[it] = in[spec_off(rr, cc, p.pitch)];   // zero selected where it is consumed, not here:
         }                                            // a select right behind the load would wait for it
     };
     int lin = order.item(0);
@@ -662,7 +691,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
             for (int it = 0; it < NLD; ++it) {
                 const int e = tid + it * NT;
                 const int row = e / C, c = e % C;
-                if (row < p.ny && col0 + c < p.kx) out[(size_t)row * p.pitch + col0 + c] = lds[c * LP + view_lds.nat(row)];
+                if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP + view_lds.nat(row)];
             }
         }
         rl_stamp(sync, 7);
@@ -695,12 +724,13 @@ struct RowSpectra {
     static constexpr int NPK = (Cfg::L / 2 + 64) / 64;   // ceil((L/2 + 1) / 64)
     cx<T> A[NPK], B[NPK];
     RL_HD void request(const RowParams<T>& p, int by, int r0, unsigned t) {
-        const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * ((size_t)p.ny * p.pitch) + (size_t)r0 * p.pitch;
-        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? p.pitch : 0);
+        const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * spec_image_elems(p.ny, p.pitch) + spec_pair_off(r0 >> 1, p.pitch);
+        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? spec_odd_row(p.pitch) : 0u);
+        const unsigned lane = spec_pair_col(t);
 #pragma unroll
         for (int it = 0; it < NPK; ++it) {
-            A[it] = sa[t + it * 64];
-            B[it] = sb[t + it * 64];
+            A[it] = sa[lane + it * SPEC_PAIR_STEP64];
+            B[it] = sb[lane + it * SPEC_PAIR_STEP64];
         }
     }
 };
@@ -723,7 +753,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
     static_assert(!F0::TAIL, "the pass that touches the images must be lane-local");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
     constexpr int NPK = RowSpectra<Cfg, T>::NPK;
-    const size_t simg = (size_t)p.ny * p.pitch, rimg = (size_t)p.ny * p.nx;
+    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
     const int r1 = r0 + 1;
     const bool ok1 = r1 < p.ny;
     rl_stamp(sync, 0);
@@ -809,15 +839,16 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
         }
     }
     fft_sync<Cfg>(sync);
-    cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
-    cx<T>* __restrict__ so1 = so0 + p.pitch;
+    cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + spec_pair_off(r0 >> 1, p.pitch);
+    cx<T>* __restrict__ so1 = so0 + spec_odd_row(p.pitch);
+    const unsigned lane_so = spec_pair_col(t);
 #pragma unroll
     for (int it = 0; it < NPK; ++it) {
         const int kk = tl_ + it * 64;
         if (kk <= L / 2) {
             const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
-            so0[t + it * 64] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
-            if (ok1) so1[t + it * 64] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+            so0[lane_so + it * SPEC_PAIR_STEP64] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
+            if (ok1) so1[lane_so + it * SPEC_PAIR_STEP64] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
         }
     }
     rl_stamp(sync, 5);

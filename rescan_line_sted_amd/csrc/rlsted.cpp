@@ -65,8 +65,8 @@ struct rl_deconv {
     void *twy = nullptr, *twx = nullptr;
     // device buffers (element type = dtype)
     void* psf_hat = nullptr;   // [V][ly][pitch] complex
-    void* spec_a = nullptr;    // [B][ny][pitch] complex
-    void* spec_b = nullptr;    // [B*V][ny][pitch] complex
+    void* spec_a = nullptr;    // [B] spectrum images (layout: conv_kernels.hpp spec_off)
+    void* spec_b = nullptr;    // [B*V] spectrum images
     void* obj = nullptr;       // [B][ny][nx]
     void* noiseless = nullptr; // [B*V][ny][nx]
     void* meas = nullptr;      // [B*V][ny][nx]
@@ -107,7 +107,7 @@ struct rl_deconv {
     double last_iter_ms = 0, last_sim_ms = 0;
 
     size_t n_img() const { return (size_t)ny * nx; }
-    size_t n_spec() const { return (size_t)ny * pitch; }
+    size_t n_spec() const { return spec_image_elems(ny, pitch); }   // complex elements of one spectrum image
 
     enum ColKind { COL_H, COL_HT_VIEW, COL_HT_FUSED };
     bool wave_private_y() const { return ty->psf_transposed != 0; }   // multi-view modes exist there only

@@ -190,6 +190,9 @@ extern "C" {
 // stand in for the tiled ones wherever rlsted.cpp would launch them; 0: tiled bodies
 void emu_set_stream(int nwg) { g_stream_nwg = nwg; }
 
+// 1: spectra are in the blocked layout of conv_kernels.hpp (RL_SPEC_BLOCKED), 0: row-major
+int emu_spec_blocked() { return RL_SPEC_BLOCKED; }
+
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
 #define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return WavePrivate<CfgFor<LL>::Cfg>::value ? 1 : 0;

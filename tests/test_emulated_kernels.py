@@ -79,8 +79,41 @@ class EmuPlan:
         else:
             self.psf_hat = ph
 
+    # Spectra live in device memory in the layout of conv_kernels.hpp (spec_off): row-major, or --
+    # RL_SPEC_BLOCKED builds -- [row pair][8-column block][row parity][8 columns] with the rows
+    # padded to an even count.  The tests keep natural (n, ny, pitch) arrays; they are converted at
+    # the kernel boundary.
+    def _to_blocked(self, nat):
+        if not self.lib.emu_spec_blocked():          # row-major build: only the slack is added
+            return _slack(nat)
+        n, nye = nat.shape[0], (self.ny + 1) // 2 * 2
+        full = np.full((n, nye, self.pitch), np.nan + 1j * np.nan, dtype=self.ct)
+        full[:, :self.ny] = nat
+        return _slack(full.reshape(n, nye // 2, 2, self.pitch // 8, 8).transpose(0, 1, 3, 2, 4))
+
+    def _to_natural(self, blk):
+        if not self.lib.emu_spec_blocked():
+            return blk
+        n, nye = blk.shape[0], (self.ny + 1) // 2 * 2
+        return blk.reshape(n, nye // 2, self.pitch // 8, 2, 8).transpose(0, 1, 3, 2, 4).reshape(n, nye, self.pitch)[:, :self.ny]
+
+    def _spectra(self, spec_in, spec_out):
+        bin_ = self._to_blocked(spec_in) if spec_in is not None else None
+        bout = bin_ if (spec_out is spec_in and spec_in is not None) else (
+            self._to_blocked(spec_out) if spec_out is not None else None)
+        return bin_, bout
+
     def row(self, mode, gy, spec_in=None, spec_out=None, src=None, dst=None,
             norm=None, scale=None):
+        nat_out = spec_out
+        spec_in, spec_out = self._spectra(spec_in, spec_out)
+        try:
+            self._row(mode, gy, spec_in, spec_out, src, dst, norm, scale)
+        finally:
+            if nat_out is not None:
+                nat_out[...] = self._to_natural(spec_out)
+
+    def _row(self, mode, gy, spec_in, spec_out, src, dst, norm, scale):
         f = getattr(self.lib, 'emu_row_' + self.sfx)
         rc = f(self.Lx, mode, _p(spec_in) if spec_in is not None else None,
                _p(spec_out) if spec_out is not None else None,
@@ -92,6 +125,14 @@ class EmuPlan:
         assert rc == 0
 
     def col(self, spec_in, spec_out, frames, kind):
+        nat_out = spec_out
+        spec_in, spec_out = self._spectra(spec_in, spec_out)
+        try:
+            self._col(spec_in, spec_out, frames, kind)
+        finally:
+            nat_out[...] = self._to_natural(spec_out)
+
+    def _col(self, spec_in, spec_out, frames, kind):
         """kind: 'H' (frame spectrum -> V images), 'HT' (per view), 'HT_SUM' (views summed in
         the Fourier domain -> one image per frame).  Same mode selection as rlsted.cpp col_t()."""
         if kind is True:
