@@ -79,7 +79,7 @@ struct ColParams {
     int in_sb, in_sv;       // COL_PER_IMAGE: input image index = frame*in_sb + view*in_sv
     int mode;               // ColMode (wave-private column kernel only; others: per image)
     int images;             // streaming kernel: output images covered by the launch (grid.y of the tiled kernel)
-    int order;              // tiled kernel's work order: 0 image-major (default), 1 tile-major (RLSTED_COL_ORDER)
+    int order;              // tiled kernel's work order: images per block of the tile order (1 = image-major)
 };
 
 template <class Cfg, int C, typename T, class Sync>

@@ -50,27 +50,32 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && WaveP
     using KCfg = typename CfgFor<L>::Cfg;
     // XCD-aware work order (pure speed heuristic -- any placement is correct).  Workgroups are dealt
     // round-robin over the 8 XCDs, so linear ids l and l+8 share an L2; every XCD gets a contiguous
-    // range of the item sequence.  Image-major (p.order == 0, default): tile after tile of one image,
-    // then the next image -- the two tiles that share every 128-B line of the spectrum rows (64 B
-    // each) are neighbours.  Tile-major (p.order == 1): for tile pair, for image, for the two tiles
-    // of the pair -- additionally keeps the psf_hat columns of an XCD's few tiles in its L2
-    // (image-major streams the whole 1.33 MB psf_hat through every XCD once per image).
+    // range of the item sequence.  The images of the launch are taken in blocks of G = p.order:
+    //     for image block:  for tile pair:  for image in block:  for the two tiles of the pair
+    // G = 1 is image-major (tile after tile of one image): concurrent workgroups touch neighbouring
+    // 64-B segments of the same spectrum rows.  Larger G re-uses the psf_hat columns of a tile pair
+    // for G images in a row: image-major streams the whole 1.33 MB psf_hat through every XCD once
+    // per image, past ~3.7 MB of tile traffic in a 4 MiB L2 (half of it is fetched again).
+    // G >= images is tile-major: psf_hat stays resident but concurrent workgroups scatter 64-B
+    // accesses over all images.
     unsigned bx = blockIdx.x, by = blockIdx.y;
     const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
     if (total % 8 == 0) {
         const unsigned lin = by * gx + bx;
         const unsigned w = (lin % 8) * (total / 8) + lin / 8;
-        const unsigned paired = (gx & ~1u) * gy;          // items that belong to full tile pairs
-        if (p.order == 0) {
-            bx = w % gx;
-            by = w / gx;
-        } else if (w < paired) {
-            const unsigned pr = w / (2 * gy), q = w % (2 * gy);
+        // images in blocks of G = p.order: within a block, for tile pair: for image: the two tiles
+        const unsigned G = p.order < 1 ? 1u : (unsigned)p.order;
+        const unsigned blk = w / (gx * G), first = blk * G;
+        const unsigned g = gy - first < G ? gy - first : G;          // images in this block
+        const unsigned v = w - blk * gx * G;
+        const unsigned paired = (gx & ~1u) * g;                       // items of full tile pairs
+        if (v < paired) {
+            const unsigned pr = v / (2 * g), q = v % (2 * g);
             bx = 2 * pr + (q & 1u);
-            by = q >> 1;
+            by = first + (q >> 1);
         } else {
             bx = gx - 1;
-            by = w - paired;
+            by = first + (v - paired);
         }
     }
     if constexpr (WavePrivate<KCfg>::value)

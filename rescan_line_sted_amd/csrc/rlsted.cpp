@@ -95,10 +95,10 @@ struct rl_deconv {
     void *key_seeds = nullptr, *key_ids = nullptr;    // per-frame Philox keys of rl_deconv_simulate_keyed
     size_t slice_ws_bytes = 0, slice_ws_stride = 0;
     hipStream_t cur() const { return active ? active : ctx->stream; }
-    // column kernel work order: 0 image-major, 1 tile-major (RLSTED_COL_ORDER).  Tile-major keeps the
-    // psf_hat columns of an XCD's tiles in its L2 (column reads 1.90 -> 1.67 MB/frame) but measures
-    // 1.4 % slower end to end, so image-major stays the default.
-    int col_order = 0;
+    // column kernel work order: images per block of the tile order (fft_kernels.hip k_colconv):
+    // 1 image-major ... >= images per launch: tile-major (RLSTED_COL_ORDER).  Measured at 512^2, 32-frame
+    // slices: 1: 16.80 k, 2: 16.88 k, 4: 16.98 k, 8: 16.81 k, 32: 16.56 k frames/s.
+    int col_order = 4;
     bool inplace = true;     // single-view RL iterations entirely in spec_a (RLSTED_INPLACE=0: spec_a -> spec_b -> spec_a)
     bool est_ready = false;    // est holds a valid estimate
     bool spec_valid = false;   // spec_a holds rowFFT(est)
@@ -540,7 +540,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
     if (getenv("RLSTED_STREAM")) h->streaming = atoi(getenv("RLSTED_STREAM"));
     if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
-    if (getenv("RLSTED_COL_ORDER")) h->col_order = atoi(getenv("RLSTED_COL_ORDER")) != 0;
+    if (getenv("RLSTED_COL_ORDER")) h->col_order = atoi(getenv("RLSTED_COL_ORDER")) < 1 ? 1 : atoi(getenv("RLSTED_COL_ORDER"));
     if (getenv("RLSTED_LANES")) {
         h->lanes = atoi(getenv("RLSTED_LANES"));
         if (h->lanes < 1) h->lanes = 1;

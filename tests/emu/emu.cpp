@@ -95,7 +95,7 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     p.mode = mode;
     const int gy = (mode == COL_PER_IMAGE) ? frames * V : frames;   // as rlsted.cpp col_t()
     if (mode != COL_PER_IMAGE && !WavePrivate<Cfg>::value) return -3;
-    p.images = gy; p.order = 0;
+    p.images = gy; p.order = 1;
     if constexpr (WavePrivate<Cfg>::value) {
         if (g_stream_nwg > 0 && mode == COL_PER_IMAGE) {
             const int nwg = g_stream_nwg;

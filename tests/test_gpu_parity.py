@@ -229,7 +229,7 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
     for stream, inplace, lanes, mb in (('0', '1', '2', '108'), ('7', '1', '2', '108'), ('7', '0', '1', '10'),
                                        ('0', '0', '2', '10'), ('5', '1', '4', '10'), ('2', '0', '3', '20'),
                                        ('0', '1', '1', '100000')):
-        monkeypatch.setenv('RLSTED_COL_ORDER', '1' if mb in ('10', '100000') else '0')   # tile- / image-major tiles
+        monkeypatch.setenv('RLSTED_COL_ORDER', {'10': '3', '100000': '64'}.get(mb, '1'))   # image blocks of the tile order
         monkeypatch.setenv('RLSTED_STREAM', stream)
         monkeypatch.setenv('RLSTED_INPLACE', inplace)
         monkeypatch.setenv('RLSTED_LANES', lanes)

@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
     ColParams<float> cp;
     cp.in = (const cx<float>*)spec_a; cp.out = (cx<float>*)spec_b; cp.psf_hat = (const cx<float>*)psf_hat;
     cp.tw = (const cx<float>*)tw; cp.ny = ny; cp.kx = kx; cp.pitch = pitch; cp.V = 1; cp.in_sb = 1; cp.in_sv = 0;
-    cp.mode = COL_PER_IMAGE; cp.order = 0;
+    cp.mode = COL_PER_IMAGE; cp.order = 1;
     RowParams<float> rp;
     rp.spec_in = (const cx<float>*)spec_b; rp.spec_out = (cx<float>*)spec_a; rp.src = meas; rp.dst = est; rp.norm = norm;
     rp.scale = nullptr; rp.tw = (const cx<float>*)tw; rp.ny = ny; rp.nx = nx; rp.pitch = pitch; rp.V = 1;
