@@ -138,7 +138,7 @@ def test_pmc_traffic_json_is_what_the_tool_makes_of_the_committed_counter_files(
     committed = json.load(open(os.path.join(prof, 'pmc_traffic.json')))
     out = tmp_path / 'traffic.json'
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'),
-                           os.path.join(prof, 'pmc_fetch_size_v6.csv'), os.path.join(prof, 'pmc_write_size_v6.csv'),
+                           os.path.join(prof, 'pmc_fetch_size_v7.csv'), os.path.join(prof, 'pmc_write_size_v7.csv'),
                            str(out), str(committed['frames_per_launch'])], stdout=subprocess.DEVNULL)
     again = json.load(open(out))
     assert again == committed
