@@ -23,8 +23,11 @@
 #ifndef RL_ROW_LEAN
 #define RL_ROW_LEAN 1
 #endif
+// waves/SIMD requested for the f32 per-image column kernel: 6 = three 8-wave workgroups per CU
+// (80 VGPRs, no spills; 3 x 51 KB LDS), whose load / transform / store phases overlap better than
+// two (+1.7 % end to end).  The multi-view modes spill under that bound and keep 1.
 #ifndef RL_COL_MIN_WAVES
-#define RL_COL_MIN_WAVES 1
+#define RL_COL_MIN_WAVES 6
 #endif
 #ifndef RL_CFG_L
 #error "compile with -DRL_CFG_L=<length>"
@@ -43,7 +46,7 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 // kernels of different lengths (built in separate translation units) have
 // distinct symbol names.
 template <int L, int C, int MODE, typename T>
-__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_COL_MIN_WAVES : 1)
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && MODE == COL_PER_IMAGE && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_COL_MIN_WAVES : 1)
     k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
