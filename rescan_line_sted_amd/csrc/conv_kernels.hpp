@@ -712,6 +712,9 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
 #ifndef RL_STREAM_LAUNDER_LDS
 #define RL_STREAM_LAUNDER_LDS 1   // 1: LDS lane addresses are recomputed per item (fewer registers, more VALU)
 #endif
+#ifndef RL_LEAN_EST_LATE
+#define RL_LEAN_EST_LATE 0
+#endif
 #ifndef RL_LEAN_NRM_EARLY
 #define RL_LEAN_NRM_EARLY 0   // tiled lean ROW_UPDATE: normaliser loads behind the inverse transform (fewer registers)
 #endif
@@ -761,14 +764,18 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
     cx<T> pre[NB * R];
     T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * p.nx;
     T* __restrict__ const est1 = est0 + (ok1 ? p.nx : 0);
-    {
+    auto request_pre = [&] {
         const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * p.nx : est0;
         const T* __restrict__ s1 = s0 + (ok1 ? p.nx : 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < R; ++r) pre[nb * R + r] = mk<T>(s0[t + (nb * 64 + r * NBF)], s1[t + (nb * 64 + r * NBF)]);
-    }
+    };
+    // ROW_UPDATE without NRM_EARLY requests the estimate behind the inverse transform as well
+    // (RL_LEAN_EST_LATE): 36 fewer live registers through the transform buy a fifth wave per SIMD.
+    constexpr bool PRE_LATE = MODE == ROW_UPDATE && !NRM_EARLY && RL_LEAN_EST_LATE;
+    if constexpr (!PRE_LATE) request_pre();
     // normaliser values (ROW_UPDATE): all of them requested before the first store of the pointwise
     // stage (see rowpass_body).  NRM_EARLY: together with the estimate, ahead of the inverse
     // transform, so the pointwise stage never waits for L2 -- at the price of NB*R more live
@@ -801,6 +808,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
     cx<T> tl = mk<T>((T)0, (T)0);
     run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
     rl_stamp(sync, 2);
+    if constexpr (PRE_LATE) request_pre();
     if constexpr (MODE == ROW_UPDATE && !NRM_EARLY) request_norm();
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
