@@ -42,7 +42,10 @@ struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
 #ifndef RL_576_C32
 #define RL_576_C32 8
 #endif
-    static constexpr int C32 = RL_576_C32, C64 = 4, Q32 = 4, Q64 = 4;
+#ifndef RL_576_Q32
+#define RL_576_Q32 4
+#endif
+    static constexpr int C32 = RL_576_C32, C64 = 4, Q32 = RL_576_Q32, Q64 = 4;
 };
 template <>
 struct CfgFor<1152> { // 1024 + 53
