@@ -4,7 +4,7 @@ modes x 16 seeds = 1152 frames, simulate + 20 RL iterations each, through sweep.
 counts as the figure's: point 1 view, line-descanned 1-2, line-rescanned 3-4)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_line_sted_amd import sweep
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))

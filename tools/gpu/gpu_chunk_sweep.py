@@ -2,7 +2,7 @@
 working set is iterated K times before moving on) and the kernel flavour (streaming / tiled)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from rescan_line_sted_amd import _lib

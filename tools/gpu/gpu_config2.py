@@ -6,7 +6,7 @@ computed here by the product (tune_psf + psf_report + rotation on the device), t
 given the device's own noisy measurement.  Writes gpurun_out/config2.json."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_line_sted_amd import _lib, psf
 from oracle import line_sted_oracle as orc

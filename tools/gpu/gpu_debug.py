@@ -1,6 +1,6 @@
 """Manual GPU triage helper (not a test): one subprocess per FFT length/dtype."""
 import subprocess, sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = '''
 import sys, numpy as np
 sys.path.insert(0, %r)

@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_line_sted_amd import _lib
 rng = np.random.default_rng(0)

@@ -1,7 +1,7 @@
 """Manual helper (not a test): line-rescan throughput (V views) against the slice budget."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_line_sted_amd import _lib, psf
 objs = np.load(os.path.join(ROOT, 'tests', 'golden', 'objects.npz'))

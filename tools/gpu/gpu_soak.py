@@ -2,7 +2,7 @@
 times with the same seed must leave the same bits every time (no cross-slice interference)."""
 import hashlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from rescan_line_sted_amd import _lib

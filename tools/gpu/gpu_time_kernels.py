@@ -2,7 +2,7 @@
 ablation builds whose results are garbage."""
 import os, sys, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from rescan_line_sted_amd import _lib

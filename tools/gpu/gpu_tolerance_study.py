@@ -5,7 +5,7 @@ JSON (iteration -> max|a-b|/max|b| and rms) next to the profiles.  The fp16-stor
 study is not built (spectra of ~1e7-count images exceed the fp16 range without per-frame scaling)."""
 import json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_line_sted_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
