@@ -91,6 +91,9 @@ struct rl_deconv {
     hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
     hipStream_t active = nullptr;                     // stream the kernel launch helpers use
+    hipStream_t sim_stream = nullptr;                 // run_cycle(): simulation of all slices, ahead of the RL lanes
+    std::vector<hipEvent_t> sim_done;                 // one per slice
+    bool sim_ahead = false;                           // RLSTED_SIM_AHEAD=1 (measured -4 %: see run_slices)
     void* slice_ws = nullptr;                         // per-slice Poisson work lists of run_cycle()
     void *key_seeds = nullptr, *key_ids = nullptr;    // per-frame Philox keys of rl_deconv_simulate_keyed
     size_t slice_ws_bytes = 0, slice_ws_stride = 0;
@@ -348,22 +351,51 @@ struct rl_deconv {
             slice_ws_stride = stride;
         }
         int rc = RL_OK;
+        auto simulate_slice = [&](int sl, int f0, int nf) -> int {
+            RL_TRY(forward_slice(f0, nf));
+            void* ws = (char*)slice_ws + (size_t)sl * slice_ws_stride;   // this slice's Poisson work list
+            hipError_t e = aux_poisson(dtype, off(noiseless, (size_t)f0 * V * n_img()), off(meas, (size_t)f0 * V * n_img()),
+                                       (unsigned)n_img(), (unsigned)(nf * V), (unsigned)(f0 * V), seed, rng_kind, ws, cur());
+            if (e != hipSuccess) return fail(RL_ERR_HIP, std::string("Poisson kernels: ") + hipGetErrorString(e));
+            return RL_OK;
+        };
+        // Simulation ahead of the RL lanes (RLSTED_SIM_AHEAD=1, off by default): the forward model and the
+        // Poisson draws of every slice go to a stream of their own, each slice's RL lane waits for its
+        // event.  The idea: Poisson is float64 / integer ALU work, the RL kernels memory and LDS work.
+        // Measured 16.5 k against 17.2 k frames/s: the simulations of all slices then stream 2.3 GB through
+        // the memory system while the first slices iterate, and push their working sets out of the
+        // Infinity Cache.  Slice by slice on the RL lanes (below) the same overlap happens between lanes.
+        const bool ahead = simulate && nl > 1 && sim_ahead;
+        if (ahead) {
+            if (!sim_stream) HIP_TRY(hipStreamCreateWithFlags(&sim_stream, hipStreamNonBlocking));
+            while ((int)sim_done.size() < slices) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                sim_done.push_back(ev);
+            }
+            HIP_TRY(hipStreamWaitEvent(sim_stream, fork, 0));
+            active = sim_stream;
+            for (int sl = 0, f0 = 0; f0 < B && rc == RL_OK; f0 += cf, ++sl) {
+                rc = simulate_slice(sl, f0, f0 + cf <= B ? cf : B - f0);
+                if (rc == RL_OK && hipEventRecord(sim_done[sl], sim_stream) != hipSuccess) rc = fail(RL_ERR_HIP, "hipEventRecord");
+            }
+        }
         for (int sl = 0, f0 = 0; f0 < B && rc == RL_OK; f0 += cf, ++sl) {
             const int nf = f0 + cf <= B ? cf : B - f0;
             active = nl > 1 ? lane_stream[sl % nl] : nullptr;
-            if (simulate) {
-                rc = forward_slice(f0, nf);
-                if (rc == RL_OK) {
-                    void* ws = (char*)slice_ws + (size_t)sl * slice_ws_stride;   // this slice's Poisson work list
-                    hipError_t e = aux_poisson(dtype, off(noiseless, (size_t)f0 * V * n_img()), off(meas, (size_t)f0 * V * n_img()),
-                                               (unsigned)n_img(), (unsigned)(nf * V), (unsigned)(f0 * V), seed, rng_kind, ws, cur());
-                    if (e != hipSuccess) rc = fail(RL_ERR_HIP, std::string("Poisson kernels: ") + hipGetErrorString(e));
-                }
+            if (ahead) {
+                if (hipStreamWaitEvent(lane_stream[sl % nl], sim_done[sl], 0) != hipSuccess) rc = fail(RL_ERR_HIP, "hipStreamWaitEvent");
+            } else if (simulate) {
+                rc = simulate_slice(sl, f0, nf);
             }
             if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf);
             for (int i = 0; i < k && rc == RL_OK; ++i) rc = iterate_chunk(f0, nf);
         }
         active = nullptr;
+        if (ahead) {   // on errors a lane may not have waited for every slice: join the simulation stream too
+            HIP_TRY(hipEventRecord(fork, sim_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, fork, 0));
+        }
         if (nl > 1) {   // join, also on errors: the context's stream continues after every lane
             for (int l = 0; l < nl; ++l) {
                 HIP_TRY(hipEventRecord(lane_done[l], lane_stream[l]));
@@ -445,6 +477,11 @@ int rl_deconv_destroy(rl_deconv* h) {
     hipStreamSynchronize(h->ctx->stream);
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
         if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
+    if (h->sim_stream) {
+        hipStreamSynchronize(h->sim_stream);
+        hipStreamDestroy(h->sim_stream);
+    }
+    for (hipEvent_t ev : h->sim_done) hipEventDestroy(ev);
     void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
@@ -540,6 +577,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
     if (getenv("RLSTED_STREAM")) h->streaming = atoi(getenv("RLSTED_STREAM"));
     if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
+    if (getenv("RLSTED_SIM_AHEAD")) h->sim_ahead = atoi(getenv("RLSTED_SIM_AHEAD")) != 0;
     if (getenv("RLSTED_COL_ORDER")) h->col_order = atoi(getenv("RLSTED_COL_ORDER")) < 1 ? 1 : atoi(getenv("RLSTED_COL_ORDER"));
     if (getenv("RLSTED_LANES")) {
         h->lanes = atoi(getenv("RLSTED_LANES"));

@@ -250,13 +250,14 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
         assert max_rel(est, ref) < (2e-6 if dtype == 'f32' else 1e-13), key
 
 
-@pytest.mark.parametrize('lanes,mb', [('1', '100000'), ('2', '10'), ('3', '7')])
-def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lanes, mb, monkeypatch):
+@pytest.mark.parametrize('lanes,mb,ahead', [('1', '100000', '0'), ('2', '10', '0'), ('3', '7', '1'), ('2', '10', '1')])
+def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lanes, mb, ahead, monkeypatch):
     """bench.py's timed call (rl_deconv_bench_cycles: forward model, Poisson, est = 1 and K
     iterations per slice of the batch, slices on concurrent streams) leaves exactly what
     rl_deconv_simulate + rl_deconv_iterate over the whole batch leave."""
     monkeypatch.setenv('RLSTED_LANES', lanes)
     monkeypatch.setenv('RLSTED_CHUNK_MB', mb)
+    monkeypatch.setenv('RLSTED_SIM_AHEAD', ahead)       # simulation of all slices on a stream of its own
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     rng = np.random.default_rng(17)
     B, K = 11, 4
