@@ -68,6 +68,9 @@ struct PoissonKeys {
     }
 };
 
+#ifndef RL_POISSON_NT
+#define RL_POISSON_NT 0
+#endif
 // noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510), in two launches so that
 // the rare slow path (log / log-gamma acceptance test, further attempts) does not run
 // with 13 % of the lanes active on every wave:
@@ -87,7 +90,11 @@ __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ 
     unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
     const size_t total = (size_t)n_pix * n_img;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+#if RL_POISSON_NT
+        const double lam = (double)__builtin_nontemporal_load(&noiseless[i]);   // read once: keep it out of the caches
+#else
         const double lam = (double)noiseless[i];
+#endif
         if (rng_kind != 1) {
             noisy[i] = (T)(lam + 1e-9);
             continue;
