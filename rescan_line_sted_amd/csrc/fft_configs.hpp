@@ -57,7 +57,13 @@ struct CfgFor<2304> { // 2048 + 53
     // (12,12,16) on 192 threads keeps every lane busy in two of three passes but measures the same
     // (473 vs 478 frames/s at 2048^2): the 4-column tiles (32-B row segments) bound the column pass
     using Cfg = FftCfg<2304, 256, 9, 16, 16>;
-    static constexpr int C32 = 4, C64 = 2, Q32 = 2, Q64 = 2;
+#ifndef RL_2304_C32
+#define RL_2304_C32 4
+#endif
+#ifndef RL_2304_Q32
+#define RL_2304_Q32 1   // one row pair per workgroup: 7 workgroups per CU overlap their phases (+9 % at 2048^2 over 2)
+#endif
+    static constexpr int C32 = RL_2304_C32, C64 = 2, Q32 = RL_2304_Q32, Q64 = 2;
 };
 
 template <>
