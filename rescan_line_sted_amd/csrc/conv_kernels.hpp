@@ -102,7 +102,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
     const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
     cx<T>* __restrict__ out = p.out + (size_t)by * img;
     const cx<T>* __restrict__ ph = p.psf_hat + (size_t)view * Cfg::L * p.pitch;
-    LdsView<T, C> view_lds{lds + c};
+    LdsView<T, C, false, LdsPadShift<Cfg::L>::value> view_lds{lds + c};
 
     cx<T> v[VMAX];
     cx<T> tl = mk<T>((T)0, (T)0);   // tail element (wave-private L = 576 only; unused here)
@@ -352,7 +352,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     const int r0 = 2 * (bx * Q + q), r1 = r0 + 1;
     const bool ok0 = r0 < p.ny, ok1 = r1 < p.ny;
     const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
-    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + q * LdsSlots<Cfg>::value};
+    LdsView<T, 1, LdsGather<L>::value, LdsPadShift<L>::value> view_lds{lds + q * LdsSlots<Cfg>::value};
 
     // element index held in register slot (nb, r) after an inverse / before a forward
     using IL = PassInfo<Cfg, true, NP - 1>;

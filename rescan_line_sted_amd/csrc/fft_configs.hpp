@@ -72,6 +72,16 @@ struct CfgFor<4608> { // 4096 + 53: one transform per workgroup (functional supp
     static constexpr int C32 = 1, C64 = 1, Q32 = 1, Q64 = 1;
 };
 
+// One pad slot per 16 elements for L = 2304 (RL_2304_PAD_SHIFT): 4 columns then take 78 KB instead
+// of 83 KB and two column workgroups fit a CU.
+#ifndef RL_2304_PAD_SHIFT
+#define RL_2304_PAD_SHIFT 3
+#endif
+template <>
+struct LdsPadShift<2304> {
+    static constexpr int value = RL_2304_PAD_SHIFT;
+};
+
 // LDS layout per length: the gathered exchange layout (fft_core.hpp, LdsGather) for the
 // wave-private geometries
 #ifndef RL_LDS_GATHER

@@ -189,10 +189,16 @@ struct CfgRegs {
 
 // LDS index padding: one extra slot per 8 keeps the stride-R scatter of the
 // radix-8 passes off a single bank group (LDS layout).
-RL_HD int lds_pad(int idx) { return idx + (idx >> 3); }
+// SH: one pad slot per 2^SH elements (3 unless fft_configs.hpp says otherwise for a length).
+template <int L>
+struct LdsPadShift {
+    static constexpr int value = 3;
+};
+template <int SH = 3>
+RL_HD int lds_pad(int idx) { return idx + (idx >> SH); }
 template <int L>
 struct LdsLen {
-    static constexpr int value = L + (L >> 3) + 1;
+    static constexpr int value = L + (L >> LdsPadShift<L>::value) + 1;
 };
 
 // Which LDS layout a transform length uses.  false: natural order with one pad slot per 8
@@ -211,11 +217,12 @@ struct LdsGather {
 // View of one transform's LDS storage.  CS = element stride (1 for the row
 // kernels' [fft][idx] layout, C for the column kernels' [idx][column] layout).
 // G: gathered layout (natural order unpadded).
-template <typename T, int CS, bool G = false>
+template <typename T, int CS, bool G = false, int SH = 3>
 struct LdsView {
     static constexpr bool gathered = G;
+    static constexpr int pad_shift = SH;
     cx<T>* base;
-    RL_HD static int nat(int idx) { return G ? idx : lds_pad(idx); }   // slot of natural-order element idx
+    RL_HD static int nat(int idx) { return G ? idx : lds_pad<SH>(idx); }   // slot of natural-order element idx
     RL_HD cx<T>& at(int idx) const { return base[nat(idx) * CS]; }
     RL_HD cx<T>& slot(int s) const { return base[s * CS]; }
     // Element idx0 + k*STEP, with the padded position of idx0 already known.  For a step that
@@ -225,8 +232,8 @@ struct LdsView {
     template <int STEP>
     RL_HD cx<T>& at_step(int idx0, int pad0, int k) const {
         if constexpr (G) return base[(idx0 + k * STEP) * CS];
-        else if constexpr (STEP % 8 == 0) return base[(pad0 + k * (STEP + STEP / 8)) * CS];
-        else return base[lds_pad(idx0 + k * STEP) * CS];
+        else if constexpr (STEP % (1 << SH) == 0) return base[(pad0 + k * (STEP + (STEP >> SH))) * CS];
+        else return base[lds_pad<SH>(idx0 + k * STEP) * CS];
     }
 };
 
@@ -378,11 +385,12 @@ RL_HD void pass_store_lds(const cx<T>* v, int t, View lds) {
                 for (int r = 0; r < R; ++r) lds.slot(j + r * X::S) = v[nb * R + r];
             } else {
                 const int j0 = (j / PI::NS) * (PI::NS * R) + (j % PI::NS);
-                // NS == 1, R == 8: lds_pad(8j + r) = 9j + r
-                const int p0 = (PI::NS == 1 && R == 8) ? 9 * j : lds_pad(j0);
+                // NS == 1, R == 8, one pad per 8: lds_pad(8j + r) = 9j + r
+                constexpr bool NINE = PI::NS == 1 && R == 8 && View::pad_shift == 3;
+                const int p0 = NINE ? 9 * j : View::nat(j0);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if constexpr (PI::NS == 1 && R == 8) lds.slot(p0 + r) = v[nb * R + r];
+                    if constexpr (NINE) lds.slot(p0 + r) = v[nb * R + r];
                     else lds.template at_step<PI::NS>(j0, p0, r) = v[nb * R + r];
                 }
             }
