@@ -50,7 +50,12 @@ struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
 template <>
 struct CfgFor<1152> { // 1024 + 53
     using Cfg = FftCfg<1152, 144, 8, 9, 16>;
-    static constexpr int C32 = 4, C64 = 4, Q32 = 4, Q64 = 4;   // T*C <= 1024 threads
+    // one row pair per workgroup: the row kernels of the workgroup-synchronous lengths have barriers
+    // between passes, and many small workgroups overlap them (1024^2: 2525 -> 3108 frames/s over Q = 4)
+#ifndef RL_1152_Q32
+#define RL_1152_Q32 1
+#endif
+    static constexpr int C32 = 4, C64 = 4, Q32 = RL_1152_Q32, Q64 = 1;   // T*C <= 1024 threads
 };
 template <>
 struct CfgFor<2304> { // 2048 + 53
@@ -63,7 +68,7 @@ struct CfgFor<2304> { // 2048 + 53
 #ifndef RL_2304_Q32
 #define RL_2304_Q32 1   // one row pair per workgroup: 7 workgroups per CU overlap their phases (+9 % at 2048^2 over 2)
 #endif
-    static constexpr int C32 = RL_2304_C32, C64 = 2, Q32 = RL_2304_Q32, Q64 = 2;
+    static constexpr int C32 = RL_2304_C32, C64 = 2, Q32 = RL_2304_Q32, Q64 = 1;
 };
 
 template <>
