@@ -76,16 +76,18 @@ struct rl_ctx {
     }
 
     // per-pass twiddle table of one transform length (layout: fft_core.hpp PassTw)
-    int twiddles(const rl::KernelTable* t, int dtype, void** out) {
-        auto key = std::make_pair(t->L, dtype);
+    // column == true: the table of the column kernels' geometry (fft_configs.hpp ColCfgFor)
+    int twiddles(const rl::KernelTable* t, int dtype, void** out, bool column = false) {
+        auto key = std::make_pair(t->L + (column ? (1 << 24) : 0), dtype);
         auto it = tw.find(key);
         if (it != tw.end()) {
             *out = it->second;
             return RL_OK;
         }
-        const size_t n = 2 * (size_t)(t->tw_count > 0 ? t->tw_count : 1);
+        const int count = column ? t->tw_count_col : t->tw_count;
+        const size_t n = 2 * (size_t)(count > 0 ? count : 1);
         std::vector<double> h(n, 0.0);
-        if (t->tw_count > 0) t->fill_tw(h.data());
+        if (count > 0) (column ? t->fill_tw_col : t->fill_tw)(h.data());
         void* dev = nullptr;
         if (dtype == RL_F64) {
             HIP_TRY(hipMalloc(&dev, sizeof(double) * n));

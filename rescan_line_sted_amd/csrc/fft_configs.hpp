@@ -61,9 +61,9 @@ template <>
 struct CfgFor<2304> { // 2048 + 53
     // (12,12,16) on 192 threads keeps every lane busy in two of three passes but measures the same
     // (473 vs 478 frames/s at 2048^2): the 4-column tiles (32-B row segments) bound the column pass
-    using Cfg = FftCfg<2304, 256, 9, 16, 16>;
+    using Cfg = FftCfg<2304, 256, 9, 16, 16>;   // row kernels; the column kernels use ColCfgFor<2304> below
 #ifndef RL_2304_C32
-#define RL_2304_C32 4
+#define RL_2304_C32 6
 #endif
 #ifndef RL_2304_Q32
 #define RL_2304_Q32 1   // one row pair per workgroup: 7 workgroups per CU overlap their phases (+9 % at 2048^2 over 2)
@@ -72,9 +72,9 @@ struct CfgFor<2304> { // 2048 + 53
 };
 
 template <>
-struct CfgFor<4608> { // 4096 + 53: one transform per workgroup (functional support, not tuned)
-    using Cfg = FftCfg<4608, 576, 8, 8, 8, 9>;
-    static constexpr int C32 = 1, C64 = 1, Q32 = 1, Q64 = 1;
+struct CfgFor<4608> { // 4096 + 53
+    using Cfg = FftCfg<4608, 576, 8, 8, 8, 9>;     // row kernels; columns: ColCfgFor<4608> below
+    static constexpr int C32 = 3, C64 = 1, Q32 = 1, Q64 = 1;
 };
 
 // One pad slot per 16 elements for L = 2304 (RL_2304_PAD_SHIFT): 4 columns then take 78 KB instead
@@ -101,11 +101,34 @@ struct LdsGather<576> {
     static constexpr bool value = RL_LDS_GATHER != 0;
 };
 
+// Geometry of the COLUMN kernels where it differs from the row kernels' (same length, its own radix
+// list, thread count and twiddle table).  A column workgroup holds C whole columns in LDS, so few
+// threads per transform = more columns per workgroup = wider row segments of the tile (C * 8 bytes);
+// the row kernels want the opposite, many threads per transform and the radix that touches the
+// image rows first.  Measured per 512^2-equivalent frame:
+//   2304: rows 0.98 / 1.24 us on (9,16,16) x 256 threads against 1.79 / 1.65 on (16,16,9) x 144;
+//         columns 2.6 us on the former (4 columns, 32-B segments), 2.26 on the latter (6 columns);
+//   4608: rows 1.2 / 1.7 us on (8,8,8,9) x 576 against 1.5 / 2.2 on (16,16,18) x 288;
+//         columns 6.1 us on the former (1 column, 8-B segments), 3.8 on the latter (3 columns).
+template <int L>
+struct ColCfgFor {
+    using type = typename CfgFor<L>::Cfg;
+};
+template <>
+struct ColCfgFor<2304> {
+    using type = FftCfg<2304, 144, 16, 16, 9>;
+};
+template <>
+struct ColCfgFor<4608> {
+    using type = FftCfg<4608, 288, 16, 16, 18>;
+};
+
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads
 template <int L>
 constexpr bool cfg_fits() {
     using CF = CfgFor<L>;
-    return CF::Cfg::T * CF::C32 <= 1024 && CF::Cfg::T * CF::C64 <= 1024 && CF::Cfg::T * CF::Q32 <= 1024 && CF::Cfg::T * CF::Q64 <= 1024;
+    using CC = typename ColCfgFor<L>::type;
+    return CC::T * CF::C32 <= 1024 && CC::T * CF::C64 <= 1024 && CF::Cfg::T * CF::Q32 <= 1024 && CF::Cfg::T * CF::Q64 <= 1024;
 }
 static_assert(cfg_fits<64>() && cfg_fits<192>() && cfg_fits<256>() && cfg_fits<576>() && cfg_fits<1152>() &&
                   cfg_fits<2304>() && cfg_fits<4608>(),

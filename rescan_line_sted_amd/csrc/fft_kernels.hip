@@ -36,7 +36,8 @@
 namespace rl {
 
 using CF = CfgFor<RL_CFG_L>;
-using Cfg = CF::Cfg;
+using Cfg = CF::Cfg;                               // row kernels
+using CCfg = ColCfgFor<RL_CFG_L>::type;            // column kernels
 constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 #define RL_CAT_(a, b) a##b
 #define RL_CAT(a, b) RL_CAT_(a, b)
@@ -46,11 +47,11 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 // kernels of different lengths (built in separate translation units) have
 // distinct symbol names.
 template <int L, int C, int MODE, typename T>
-__global__ void __launch_bounds__(CfgFor<L>::Cfg::T* C, (sizeof(T) == 4 && MODE == COL_PER_IMAGE && WavePrivate<typename CfgFor<L>::Cfg>::value) ? RL_COL_MIN_WAVES : 1)
+__global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && MODE == COL_PER_IMAGE && WavePrivate<typename ColCfgFor<L>::type>::value) ? RL_COL_MIN_WAVES : 1)
     k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    using KCfg = typename CfgFor<L>::Cfg;
+    using KCfg = typename ColCfgFor<L>::type;
     // XCD-aware work order (pure speed heuristic -- any placement is correct).  Workgroups are dealt
     // round-robin over the 8 XCDs, so linear ids l and l+8 share an L2; every XCD gets a contiguous
     // range of the item sequence.  The images of the launch are taken in blocks of G = p.order:
@@ -145,7 +146,7 @@ template <int L, int C, typename T>
 __global__ void __launch_bounds__(64 * C, sizeof(T) == 4 ? RL_STREAM_COL_MIN_WAVES : 1) k_colstream(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
-    colstream_body<typename CfgFor<L>::Cfg, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<T>*>(smem), s);
+    colstream_body<typename ColCfgFor<L>::type, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<T>*>(smem), s);
 }
 template <int L, int Q, int MODE, typename T>
 __global__ void __launch_bounds__(64 * Q, sizeof(T) == 4 ? RL_STREAM_ROW_MIN_WAVES : 1) k_rowstream(const RowParams<T> p) {
@@ -157,6 +158,10 @@ __global__ void __launch_bounds__(64 * Q, sizeof(T) == 4 ? RL_STREAM_ROW_MIN_WAV
 template <int N, typename T>
 static constexpr size_t stream_lds_bytes() {
     return ((size_t)N * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>);
+}
+template <int N, typename T>
+static constexpr size_t col_stream_lds_bytes() {
+    return ((size_t)N * LdsSlots<CCfg>::value + StreamTw<CCfg>::COUNT) * sizeof(cx<T>);
 }
 
 // workgroups of `fn` that the device holds at once (0 on error), a multiple of 8 (one share per XCD)
@@ -175,9 +180,9 @@ static int resident_workgroups(F* fn, int threads, size_t lds) {
 
 template <int C, typename T>
 static hipError_t launch_col_stream_t(const void* params, hipStream_t s) {
-    if constexpr (WavePrivate<Cfg>::value) {
+    if constexpr (WavePrivate<CCfg>::value) {
         const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
-        constexpr size_t lds = stream_lds_bytes<C, T>();
+        constexpr size_t lds = col_stream_lds_bytes<C, T>();
         static const int resident = resident_workgroups(k_colstream<RL_CFG_L, C, T>, 64 * C, lds);
         if (resident < 1) return hipErrorLaunchFailure;
         const long total = (long)p.images * ((p.kx + C - 1) / C);
@@ -225,16 +230,20 @@ template <int C, typename T>
 static constexpr size_t lds_bytes() {
     return (size_t)C * LdsSlots<Cfg>::value * sizeof(cx<T>);
 }
+template <int C, typename T>
+static constexpr size_t col_lds_bytes() {
+    return (size_t)C * LdsSlots<CCfg>::value * sizeof(cx<T>);
+}
 
 template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
-    if (WavePrivate<Cfg>::value && p.mode == COL_H_MULTI)
-        k_colconv<RL_CFG_L, C, COL_H_MULTI, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
-    else if (WavePrivate<Cfg>::value && p.mode == COL_HT_SUM)
-        k_colconv<RL_CFG_L, C, COL_HT_SUM, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+    if (WavePrivate<CCfg>::value && p.mode == COL_H_MULTI)
+        k_colconv<RL_CFG_L, C, COL_H_MULTI, T><<<dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s>>>(p);
+    else if (WavePrivate<CCfg>::value && p.mode == COL_HT_SUM)
+        k_colconv<RL_CFG_L, C, COL_HT_SUM, T><<<dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s>>>(p);
     else if (p.mode == COL_PER_IMAGE)
-        k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T><<<dim3(gx, gy), dim3(Cfg::T * C), lds_bytes<C, T>(), s>>>(p);
+        k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T><<<dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s>>>(p);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -295,17 +304,18 @@ static hipError_t prepare_rows() {
 
 static hipError_t prepare() {
     hipError_t e;
-    if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float>, lds_bytes<kC32, float>())) != hipSuccess) return e;
-    if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double>, lds_bytes<kC64, double>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
+    if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double>, col_lds_bytes<kC64, double>())) != hipSuccess) return e;
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
 const KernelTable* RL_TABLE_FN() {
-    static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, WavePrivate<Cfg>::value ? 1 : 0,
-                                  PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>, launch_col, launch_row, prepare,
-                                  WavePrivate<Cfg>::value ? launch_col_stream : nullptr,
+    static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, WavePrivate<CCfg>::value ? 1 : 0,
+                                  PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
+                                  PassTw<CCfg, false, 0>::TOTAL, fill_pass_twiddles<CCfg>, launch_col, launch_row, prepare,
+                                  WavePrivate<CCfg>::value ? launch_col_stream : nullptr,
                                   WavePrivate<Cfg>::value ? launch_row_stream : nullptr};
     return &t;
 }

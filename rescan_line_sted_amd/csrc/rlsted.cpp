@@ -512,7 +512,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     h->pitch = (h->kx + 7) / 8 * 8;
     RL_TRY(ctx->prepare(h->ty));
     RL_TRY(ctx->prepare(h->tx));
-    RL_TRY(ctx->twiddles(h->ty, h->dtype, &h->twy));
+    RL_TRY(ctx->twiddles(h->ty, h->dtype, &h->twy, true));
     RL_TRY(ctx->twiddles(h->tx, h->dtype, &h->twx));
     const size_t es = esize(h->dtype), B = (size_t)h->B, V = (size_t)h->V;
     struct Req { void** p; size_t n; };

@@ -68,9 +68,8 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
 // > 0: run the streaming (persistent) bodies with that many workgroups where they apply
 static int g_stream_nwg = 0;
 
-template <int L, typename T>
-static std::vector<cx<T>> twiddles() {   // the per-pass table the device plan uploads
-    using Cfg = typename CfgFor<L>::Cfg;
+template <class Cfg, typename T>
+static std::vector<cx<T>> twiddles_of() {   // the per-pass table the device plan uploads for one geometry
     constexpr int n = PassTw<Cfg, false, 0>::TOTAL;
     std::vector<double> h(2 * (size_t)(n > 0 ? n : 1), 0.0);
     if (n > 0) fill_pass_twiddles<Cfg>(h.data());
@@ -78,14 +77,19 @@ static std::vector<cx<T>> twiddles() {   // the per-pass table the device plan u
     for (size_t i = 0; i < tw.size(); ++i) tw[i] = mk<T>((T)h[2 * i], (T)h[2 * i + 1]);
     return tw;
 }
+template <int L, typename T>
+static std::vector<cx<T>> twiddles(bool column = false) {   // rows: CfgFor<L>::Cfg, columns: ColCfgFor<L>
+    if (column) return twiddles_of<typename ColCfgFor<L>::type, T>();
+    return twiddles_of<typename CfgFor<L>::Cfg, T>();
+}
 
 template <int L, typename T>
 static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitch, int V, int frames,
                  int in_sb, int in_sv, int mode) {
     using CF = CfgFor<L>;
-    using Cfg = typename CF::Cfg;
+    using Cfg = typename ColCfgFor<L>::type;      // the column kernels' geometry
     constexpr int C = sizeof(T) == 4 ? CF::C32 : CF::C64;
-    auto tw = twiddles<L, T>();
+    auto tw = twiddles<L, T>(true);
     ColParams<T> p;
     p.in = reinterpret_cast<const cx<T>*>(in);
     p.out = reinterpret_cast<cx<T>*>(out);
@@ -195,7 +199,7 @@ int emu_spec_blocked() { return RL_SPEC_BLOCKED; }
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
-#define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return WavePrivate<CfgFor<LL>::Cfg>::value ? 1 : 0;
+#define GEO(LL) case LL: *T = CfgFor<LL>::Cfg::T; *C = CfgFor<LL>::C64; *Q = CfgFor<LL>::Q64; return WavePrivate<ColCfgFor<LL>::type>::value ? 1 : 0;
     switch (L) { GEO(64) GEO(192) GEO(256) GEO(576) GEO(1152) GEO(2304) GEO(4608) }
     return -2;
 }
