@@ -25,7 +25,13 @@ struct CfgFor<192> {  // 128 + 53
     // lose the fused multi-view column modes that exist for T == 64 only).  Row kernels still
     // exchange through LDS with wave-level ordering only (WaveLocal).
     using Cfg = FftCfg<192, 16, 12, 16>;
-    static constexpr int C32 = 32, C64 = 16, Q32 = 16, Q64 = 16;
+#ifndef RL_192_C32
+#define RL_192_C32 16   // 16 columns (128-B row segments, 256 threads): +10 % over 32 at 128x128, 8 measures the same
+#endif
+#ifndef RL_192_Q32
+#define RL_192_Q32 16
+#endif
+    static constexpr int C32 = RL_192_C32, C64 = 16, Q32 = RL_192_Q32, Q64 = 16;
 };
 template <>
 struct CfgFor<256> {  // 160 + 53
