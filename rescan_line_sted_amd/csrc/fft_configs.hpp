@@ -61,7 +61,10 @@ struct CfgFor<1152> { // 1024 + 53
 #ifndef RL_1152_Q32
 #define RL_1152_Q32 1
 #endif
-    static constexpr int C32 = 4, C64 = 4, Q32 = RL_1152_Q32, Q64 = 1;   // T*C <= 1024 threads
+#ifndef RL_1152_C32
+#define RL_1152_C32 4
+#endif
+    static constexpr int C32 = RL_1152_C32, C64 = 4, Q32 = RL_1152_Q32, Q64 = 1;   // T*C <= 1024 threads
 };
 template <>
 struct CfgFor<2304> { // 2048 + 53
