@@ -51,7 +51,13 @@ struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
 #ifndef RL_576_Q32
 #define RL_576_Q32 4
 #endif
-    static constexpr int C32 = RL_576_C32, C64 = 4, Q32 = RL_576_Q32, Q64 = 4;
+#ifndef RL_576_C64
+#define RL_576_C64 4
+#endif
+#ifndef RL_576_Q64
+#define RL_576_Q64 4
+#endif
+    static constexpr int C32 = RL_576_C32, C64 = RL_576_C64, Q32 = RL_576_Q32, Q64 = RL_576_Q64;
 };
 template <>
 struct CfgFor<1152> { // 1024 + 53
