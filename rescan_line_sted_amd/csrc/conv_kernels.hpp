@@ -195,7 +195,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
             const int e = tid + it * NT;
             const int row = e / C, c = e % C;
             x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx) x[it] = in[spec_off(row, col0 + c, p.pitch)];
+            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -574,6 +574,14 @@ RL_HD int stream_launder_lane(int x) {
     return x;
 }
 
+template <typename P>
+RL_HD const P* stream_launder_ptr(const P* x) {   // a wave-uniform pointer, same purpose
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
+
 // Work item order of a persistent grid.  Workgroups are dealt round-robin over the 8 XCDs
 // (wg % 8); each XCD gets a contiguous range of items so that neighbouring tiles -- which share
 // 128-B lines -- meet in one L2.  Any order is correct.
@@ -726,14 +734,15 @@ template <class Cfg, typename T>
 struct RowSpectra {
     static constexpr int NPK = (Cfg::L / 2 + 64) / 64;   // ceil((L/2 + 1) / 64)
     cx<T> A[NPK], B[NPK];
-    RL_HD void request(const RowParams<T>& p, int by, int r0, unsigned t) {
+    template <class Sync>
+    RL_HD void request(const RowParams<T>& p, int by, int r0, unsigned t, Sync& sync) {
         const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * spec_image_elems(p.ny, p.pitch) + spec_pair_off(r0 >> 1, p.pitch);
         const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? spec_odd_row(p.pitch) : 0u);
         const unsigned lane = spec_pair_col(t);
 #pragma unroll
         for (int it = 0; it < NPK; ++it) {
-            A[it] = sa[lane + it * SPEC_PAIR_STEP64];
-            B[it] = sb[lane + it * SPEC_PAIR_STEP64];
+            A[it] = rl_ldg(sync, sa + (lane + it * SPEC_PAIR_STEP64));
+            B[it] = rl_ldg(sync, sb + (lane + it * SPEC_PAIR_STEP64));
         }
     }
 };
@@ -877,7 +886,7 @@ RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>
     const int total = p.frames * pairs, stride = nwg * Q;
     RowSpectra<Cfg, T> in;
     int item = wg * Q + q;
-    if (item < total) in.request(p, item / pairs, 2 * (item % pairs), t);
+    if (item < total) in.request(p, item / pairs, 2 * (item % pairs), t, sync);
     sync.wg();   // twiddles are in LDS; from here on the waves never meet again
     for (; item < total; item += stride) {
         const cx<T>* tw = lds + stream_launder(Q * LP);
@@ -886,7 +895,7 @@ RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>
         // re-requests itself) so that the waits of the pointwise stage can count past the loads
         const int next = item + stride < total ? item + stride : item;
         row_item<Cfg, MODE, true>(p, t, tl_, item / pairs, 2 * (item % pairs), in, view_lds, tw, sync,
-                            [&] { in.request(p, next / pairs, 2 * (next % pairs), t); });
+                            [&] { in.request(p, next / pairs, 2 * (next % pairs), t, sync); });
     }
 }
 
@@ -903,7 +912,7 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     const int r0 = 2 * (bx * Q + q);
     if (r0 >= p.ny) return;   // whole wave; the wave-private row kernels have no workgroup barrier
     RowSpectra<Cfg, T> in;
-    in.request(p, by, r0, t);
+    in.request(p, by, r0, t, sync);
     row_item<Cfg, MODE, RL_LEAN_NRM_EARLY != 0>(p, t, (int)t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync, [] {});
 }
 

@@ -457,6 +457,17 @@ RL_HD void rl_stamp_impl(Sync&, int, long) {}
 template <class Sync>
 RL_HD void rl_stamp(Sync& s, int k) { rl_stamp_impl(s, k, 0); }
 
+// Optional load policy for the spectrum loads of the kernel bodies: a Sync policy that has
+// ldg(const cx<T>*) (the fused Richardson-Lucy kernel: loads that bypass the CU's L1, because the
+// spectra are handed from workgroup to workgroup inside one launch) is used for them; every
+// other policy loads plainly.
+template <class Sync, typename T>
+RL_HD auto rl_ldg_impl(Sync& s, const cx<T>* p, int) -> decltype(s.ldg(p)) { return s.ldg(p); }
+template <class Sync, typename T>
+RL_HD cx<T> rl_ldg_impl(Sync&, const cx<T>* p, long) { return *p; }
+template <class Sync, typename T>
+RL_HD cx<T> rl_ldg(Sync& s, const cx<T>* p) { return rl_ldg_impl(s, p, 0); }
+
 template <class Cfg, class Sync>
 RL_HD void fft_sync(Sync& sync) {
     if constexpr (WaveLocal<Cfg>::value) sync.wave();

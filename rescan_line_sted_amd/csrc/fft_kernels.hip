@@ -6,6 +6,7 @@
 #include "conv_kernels.hpp"
 #include "fft_configs.hpp"
 #include "dev_sync.hpp"
+#include "fused_rl.hpp"
 
 // waves/SIMD requested for the f32 ROW_RATIO kernel (needs <= 96 VGPRs, which it has
 // within 2 registers; the other modes spill under that bound and are left alone)
@@ -178,6 +179,48 @@ static int resident_workgroups(F* fn, int threads, size_t lds) {
     return n >= 8 ? n / 8 * 8 : n;
 }
 
+// ---- fused Richardson-Lucy loop (fused_rl.hpp) ----
+#ifndef RL_FUSED_NW
+#define RL_FUSED_NW 8     // waves per workgroup = columns per tile = row pairs per workgroup round
+#endif
+#ifndef RL_FUSED_MIN_WAVES
+#define RL_FUSED_MIN_WAVES 4   // waves per SIMD asked of the register allocator (2 workgroups of 8 waves per CU)
+#endif
+template <int L, int NW, bool ACQ>
+__global__ void __launch_bounds__(64 * NW, RL_FUSED_MIN_WAVES) k_rl_fused(const FusedParams<float> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using KCfg = typename CfgFor<L>::Cfg;
+    constexpr size_t tile = (size_t)NW * LdsSlots<KCfg>::value * sizeof(cx<float>);
+    fused_rl_body<KCfg, NW, ACQ, float>(p, reinterpret_cast<cx<float>*>(smem), reinterpret_cast<int*>(smem + tile));
+}
+
+template <bool ACQ>
+static hipError_t launch_fused_t(const FusedParams<float>& p, int wgs_per_cu, hipStream_t s, int* grid_out) {
+    if constexpr (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) {
+        constexpr size_t lds = (size_t)RL_FUSED_NW * LdsSlots<Cfg>::value * sizeof(cx<float>) + 16;
+        auto* fn = k_rl_fused<RL_CFG_L, RL_FUSED_NW, ACQ>;
+        static const int resident = resident_workgroups(fn, 64 * RL_FUSED_NW, lds);
+        if (resident < 8) return hipErrorLaunchFailure;
+        int dev = 0, cus = 0;
+        hipError_t e;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        int grid = resident;
+        if (wgs_per_cu > 0 && wgs_per_cu * cus < grid) grid = wgs_per_cu * cus / 8 * 8;
+        if (grid < 8) return hipErrorLaunchFailure;
+        if ((e = hipMemsetAsync(p.ctrl, 0, kFusedCtrlWords * sizeof(unsigned), s)) != hipSuccess) return e;
+        fn<<<dim3((unsigned)grid), dim3(64 * RL_FUSED_NW), lds, s>>>(p);
+        if (grid_out) *grid_out = grid;
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+static hipError_t launch_fused(const void* params, int wgs_per_cu, int acquire, hipStream_t s, int* grid_out) {
+    const FusedParams<float>& p = *static_cast<const FusedParams<float>*>(params);
+    return acquire ? launch_fused_t<true>(p, wgs_per_cu, s, grid_out) : launch_fused_t<false>(p, wgs_per_cu, s, grid_out);
+}
+
 template <int C, typename T>
 static hipError_t launch_col_stream_t(const void* params, hipStream_t s) {
     if constexpr (WavePrivate<CCfg>::value) {
@@ -316,7 +359,8 @@ const KernelTable* RL_TABLE_FN() {
                                   PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
                                   PassTw<CCfg, false, 0>::TOTAL, fill_pass_twiddles<CCfg>, launch_col, launch_row, prepare,
                                   WavePrivate<CCfg>::value ? launch_col_stream : nullptr,
-                                  WavePrivate<Cfg>::value ? launch_row_stream : nullptr};
+                                  WavePrivate<Cfg>::value ? launch_row_stream : nullptr,
+                                  (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) ? launch_fused : nullptr};
     return &t;
 }
 

@@ -28,6 +28,12 @@ struct KernelTable {
     // occupancy of the kernel; params carry the image count (ColParams::images / RowParams::frames).
     hipError_t (*launch_col_stream)(int dtype, const void* params, hipStream_t s);
     hipError_t (*launch_row_stream)(int dtype, int mode, const void* params, hipStream_t s);
+    // Fused Richardson-Lucy loop (fused_rl.hpp; f32, one view, wave-private lengths, ly == lx): one
+    // persistent launch runs all iterations of all frames.  params: FusedParams<float>; the control
+    // block is zeroed on the stream first.  wgs_per_cu: requested residency (clamped to what the
+    // occupancy query allows); acquire: 1 = plain loads behind buffer_inv sc1, 0 = sc1 loads.
+    // nullptr when the length has none.
+    hipError_t (*launch_fused)(const void* params, int wgs_per_cu, int acquire, hipStream_t s, int* grid_out);
 };
 
 const KernelTable* table_64();
