@@ -41,6 +41,7 @@ extern "C" {
 
 typedef struct rl_ctx rl_ctx;
 typedef struct rl_deconv rl_deconv;
+typedef struct rl_comm rl_comm;
 
 const char* rl_last_error(void);
 int rl_version(void);
@@ -114,6 +115,53 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
  * plan; *dtype = RL_F32 / RL_F64 element type.  Synchronise the context first. */
 int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements, int* dtype);
 
+/* Plan geometry: frames per plan, views per frame, image shape.                */
+int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx);
+
+/* ---- parameter sweeps: line_sted_figure_2.py:39-57 ---------------------------
+ * The reference's figure script builds one Deconvolver per (PSF set, test image) and runs
+ * create_data_from_object + N x iterate on each.  A task is one such simulation for a plan's PSF
+ * set and image shape: an object [ny][nx] (host, float64), its total brightness (:505-506; <= 0:
+ * no scaling -- then for every task of the call), and the Philox key (seed, image_id) of its noise
+ * (rl_deconv_simulate_keyed).  rl_batch_run works through n_tasks tasks in chunks of the plan's
+ * batch: objects -> H -> Poisson -> k_iters Richardson-Lucy iterations from estimate = 1, and
+ * writes the estimates [n_tasks][ny][nx] to estimates_out (NULL: the last chunk stays in the
+ * plan's buffers for rl_gather).  A task's result does not depend on its position in the list. */
+typedef struct rl_task {
+    const double* object;
+    double total_brightness;
+    uint64_t seed;
+    uint32_t image_id;
+} rl_task;
+int rl_batch_run(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, double* estimates_out);
+
+/* ---- multi-GPU: one process per GPU, frames sharded over ranks -----------------
+ * The reference is single process; independent simulations shard with no
+ * data-path collective and ONE gather of the results at the end (section 8e).  RCCL over xGMI,
+ * loaded on first use.  rl_comm_unique_id on one rank produces RL_COMM_ID_BYTES bytes that every
+ * rank passes to rl_comm_create (a collective call: all ranks of the world enter it together).   */
+#define RL_COMM_ID_BYTES 128
+int rl_comm_unique_id(void* id128);
+int rl_comm_create(rl_ctx* ctx, int rank, int world, const void* id128, rl_comm** out);
+int rl_comm_destroy(rl_comm* c);
+int rl_comm_info(const rl_comm* c, int* rank, int* world);
+/* device-synchronise this rank, then meet every other rank (the timing harness' barrier) */
+int rl_comm_barrier(rl_comm* c);
+/* *value = max over ranks of *value (every rank gets the result)                       */
+int rl_comm_allreduce_max(rl_comm* c, double* value);
+/* Gather the first counts[r] frames of every rank r's plan buffer `which` (as in
+ * rl_deconv_device_ptr) on `root`, rank-major, straight from the device buffers: every rank sends
+ * to the root, the root receives on all its links at once.  rl_gather delivers float64 on the
+ * root's host (host_out: sum(counts) frames; ignored on other ranks); rl_gather_device leaves the
+ * result in a device buffer owned by the communicator (root: *dev_out, valid until the next gather;
+ * other ranks: NULL) in the plan's dtype.                                                */
+int rl_gather(rl_comm* c, rl_deconv* plan, int which, int root, const int* counts, double* host_out);
+int rl_gather_device(rl_comm* c, rl_deconv* plan, int which, int root, const int* counts, void** dev_out,
+                     size_t* n_elements, int* dtype);
+/* The same for host arrays (results that no longer live in a plan, e.g. a sweep's stack of frames
+ * of several shapes): counts[r] float64 values of rank r's `local`, rank-major into `out` on root. */
+int rl_comm_gather_host(rl_comm* c, const double* local, const size_t* counts, int root, double* out);
+
 /* ---- PSF generation: line_sted_tools.py:75-363, 653-668 ---------------------
  * get_width (:653-668): MINPACK-lmdif fit of A*exp(-(x-mu)^2/(2 sigma^2)) to
  * y[0..n-1] from [1, n/2, 1] with scipy.optimize.curve_fit's defaults; host
@@ -176,6 +224,16 @@ int rl_spline_sample(rl_ctx* ctx, const double* image, int ny, int nx, const dou
  * FWD and Poisson run over the whole batch).  avg_ms must hold 7 doubles.
  * Destroys the current estimate (the next iterate restarts from 1).          */
 int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms);
+
+/* In-situ kernel durations of ONE whole cycle (simulate + k iterations, as rl_deconv_bench_cycles
+ * runs it): a hipEvent pair around every launch, recorded on the stream the launch goes to, with
+ * the batch slices overlapping on their streams as in production -- the figure a rocprofv3 kernel
+ * trace of the same run reports.  avg_ms[8] / launches[8] (may be NULL): average duration and
+ * number of launches of { column pass (H), row pass RATIO, column pass (H_t), row pass UPDATE, row
+ * pass FWD, row pass INV, Poisson (both kernels), fused Richardson-Lucy loop };
+ * *frames_per_launch: frames one launch of the RL kernels covers.                        */
+int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, double* avg_ms, double* launches,
+                         double* frames_per_launch);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ def jobs():
     out.append((os.path.join(OBJ, 'aux_kernels.o'), os.path.join(CSRC, 'aux_kernels.hip'), DEVICE))
     out.append((os.path.join(OBJ, 'psf_kernels.o'), os.path.join(CSRC, 'psf_kernels.hip'), DEVICE))
     out.append((os.path.join(OBJ, 'rlsted.o'), os.path.join(CSRC, 'rlsted.cpp'), ['-x', 'hip'] + DEVICE))
+    out.append((os.path.join(OBJ, 'comm.o'), os.path.join(CSRC, 'comm.cpp'), ['-x', 'hip'] + DEVICE))
     out.append((os.path.join(OBJ, 'psf_api.o'), os.path.join(CSRC, 'psf_api.cpp'), ['-x', 'hip'] + DEVICE))
     out.append((os.path.join(OBJ, 'quality_kernels.o'), os.path.join(CSRC, 'quality_kernels.hip'), DEVICE))
     out.append((os.path.join(OBJ, 'quality_api.o'), os.path.join(CSRC, 'quality_api.cpp'), ['-x', 'hip'] + DEVICE))
@@ -76,7 +77,7 @@ def build(force=False, verbose=False):
                     print('compiled', os.path.relpath(o, ROOT))
     objs = [o for o, _, _ in jobs()]
     if force or todo or _stale(LIB, objs):
-        _run([HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH] + objs + ['-o', LIB])
+        _run([HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH] + objs + ['-ldl', '-o', LIB])
         if verbose:
             print('linked', os.path.relpath(LIB, ROOT))
     return LIB

@@ -45,7 +45,19 @@ PROTOTYPES = {
     'rl_deconv_last_ms': (_i, [_vp, _dp, _dp]),
     'rl_deconv_bench_cycles': (_i, [_vp, _i, _i, _i, _c.c_uint64, _dp]),
     'rl_deconv_time_kernels': (_i, [_vp, _i, _dp]),
+    'rl_deconv_time_cycle': (_i, [_vp, _i, _i, _c.c_uint64, _dp, _dp, _dp]),
     'rl_deconv_device_ptr': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
+    'rl_deconv_dims': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    'rl_batch_run': (_i, [_vp, _vp, _i, _i, _i, _dp]),
+    'rl_comm_unique_id': (_i, [_vp]),
+    'rl_comm_create': (_i, [_vp, _i, _i, _vp, _c.POINTER(_vp)]),
+    'rl_comm_destroy': (_i, [_vp]),
+    'rl_comm_info': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i)]),
+    'rl_comm_barrier': (_i, [_vp]),
+    'rl_comm_allreduce_max': (_i, [_vp, _dp]),
+    'rl_gather': (_i, [_vp, _vp, _i, _i, _c.POINTER(_i), _dp]),
+    'rl_gather_device': (_i, [_vp, _vp, _i, _i, _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
+    'rl_comm_gather_host': (_i, [_vp, _dp, _c.POINTER(_c.c_size_t), _i, _dp]),
     'rl_gauss_fit': (_i, [_dp, _i, _dp, _c.POINTER(_i)]),
     'rl_gaussian_filter': (_i, [_vp, _dp, _dp, _i, _i, _i, _dp, _c.c_double]),
     'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
@@ -208,16 +220,41 @@ class DeconvPlan:
         check(lib.rl_deconv_simulate_keyed(self.handle, rng, seeds.ctypes.data_as(_c.POINTER(_c.c_uint64)),
                                            ids.ctypes.data_as(_c.POINTER(_c.c_uint32))))
 
+    class _Task(_c.Structure):      # rl_task of include/rlsted.h
+        _fields_ = [('object', _dp), ('total_brightness', _c.c_double), ('seed', _c.c_uint64), ('image_id', _c.c_uint32)]
+
+    def batch_run(self, objects, total_brightness, seeds, image_ids, iterations, rng=RNG_PHILOX, fetch=True):
+        """rl_batch_run: one simulate + `iterations` x iterate cycle per task, any number of tasks, in
+        chunks of the plan's batch.  objects: (n, ny, nx); seeds / image_ids / total_brightness: scalars
+        or n values.  Returns the (n, ny, nx) estimates (fetch=False: None, the last chunk stays on the
+        device)."""
+        objects = as_f64(objects).reshape(-1, self.ny, self.nx)
+        n = objects.shape[0]
+        tb = np.broadcast_to(np.asarray(0.0 if total_brightness is None else total_brightness, dtype=np.float64), (n,))
+        seeds = np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (n,))
+        ids = np.broadcast_to(np.asarray(image_ids, dtype=np.uint32), (n,))
+        tasks = (self._Task * n)()
+        for i in range(n):
+            tasks[i].object = objects[i].ctypes.data_as(_dp)
+            tasks[i].total_brightness = float(tb[i])
+            tasks[i].seed = int(seeds[i])
+            tasks[i].image_id = int(ids[i])
+        out = np.empty((n, self.ny, self.nx), dtype=np.float64) if fetch else None
+        check(lib.rl_batch_run(self.handle, _c.cast(tasks, _vp), n, int(iterations), rng, ptr(out) if fetch else None))
+        return out
+
     def bench_cycles(self, k, reps, rng=RNG_PHILOX, seed=0):
         ms = _c.c_double()
         check(lib.rl_deconv_bench_cycles(self.handle, int(k), int(reps), rng, _c.c_uint64(seed), ctypes.byref(ms)))
         return ms.value
 
+    BUFFERS = {'estimate': 0, 'measurement': 1, 'noiseless': 2, 'object': 3}
+
     def device_array(self, which='estimate'):
         """Zero-copy view of a plan buffer as an object with __cuda_array_interface__
-        (torch.as_tensor(x, device='cuda') wraps it); the plan keeps ownership."""
+        (anything that speaks that protocol can wrap it); the plan keeps ownership."""
         from .sharding import DeviceArray
-        idx = {'estimate': 0, 'measurement': 1, 'noiseless': 2, 'object': 3}[which]
+        idx = self.BUFFERS[which]
         p, n, dt = _vp(), _c.c_size_t(), _i()
         check(lib.rl_deconv_device_ptr(self.handle, idx, ctypes.byref(p), ctypes.byref(n), ctypes.byref(dt)))
         shape = (self.B, self.ny, self.nx) if idx in (0, 3) else (self.B, self.V, self.ny, self.nx)
@@ -225,6 +262,16 @@ class DeconvPlan:
         return DeviceArray(p.value, shape, '<f4' if dt.value == RL_F32 else '<f8', self)
 
     KERNEL_NAMES = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'poisson')
+
+    CYCLE_KERNELS = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'rowpass_INV',
+                     'poisson', 'rl_fused')
+
+    def time_cycle(self, k, rng=RNG_PHILOX, seed=0):
+        """rl_deconv_time_cycle: {kernel: (average ms per launch, launches)} of one whole cycle measured with
+        HIP events on the streams the launches go to, and the frames an RL launch covers."""
+        avg, cnt, fpl = np.zeros(8), np.zeros(8), _c.c_double()
+        check(lib.rl_deconv_time_cycle(self.handle, int(k), rng, _c.c_uint64(seed), ptr(avg), ptr(cnt), ctypes.byref(fpl)))
+        return {n: (float(a), int(c)) for n, a, c in zip(self.CYCLE_KERNELS, avg, cnt) if c > 0}, int(fpl.value)
 
     def time_kernels(self, reps=20):
         out = np.zeros(7, dtype=np.float64)

@@ -2,6 +2,7 @@
 // -DRL_CFG_L=<L>).  Column pass (FFT_y * psf_hat -> IFFT_y) and the fused row
 // passes (IFFT_x -> Richardson-Lucy pointwise step -> FFT_x) of the
 // convolution path; bodies in conv_kernels.hpp.
+#include <hip/hip_ext.h>
 #include "kernel_table.hpp"
 #include "conv_kernels.hpp"
 #include "fft_configs.hpp"
@@ -35,6 +36,20 @@
 #endif
 
 namespace rl {
+
+// Every kernel of this file is launched through here.  When the caller has armed a pair of timing
+// events (kernel_table.hpp: launch_timing), the launch records the kernel's own begin and end on
+// them -- the interval a rocprofv3 kernel trace reports -- instead of stream-order timestamps.
+template <typename K, typename P>
+static void rl_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, P p) {
+    LaunchTiming& t = launch_timing();
+    if (t.start && t.stop) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, t.start, t.stop, 0, p);
+        t.start = t.stop = nullptr;   // one launch per arming
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, p);
+    }
+}
 
 using CF = CfgFor<RL_CFG_L>;
 using Cfg = CF::Cfg;                               // row kernels
@@ -209,7 +224,7 @@ static hipError_t launch_fused_t(const FusedParams<float>& p, int wgs_per_cu, hi
         if (wgs_per_cu > 0 && wgs_per_cu * cus < grid) grid = wgs_per_cu * cus / 8 * 8;
         if (grid < 8) return hipErrorLaunchFailure;
         if ((e = hipMemsetAsync(p.ctrl, 0, kFusedCtrlWords * sizeof(unsigned), s)) != hipSuccess) return e;
-        fn<<<dim3((unsigned)grid), dim3(64 * RL_FUSED_NW), lds, s>>>(p);
+        rl_launch(fn, dim3((unsigned)grid), dim3(64 * RL_FUSED_NW), lds, s, p);
         if (grid_out) *grid_out = grid;
         return hipGetLastError();
     } else {
@@ -232,7 +247,7 @@ static hipError_t launch_col_stream_t(const void* params, hipStream_t s) {
         if (total < 1) return hipSuccess;
         long nwg = total < resident ? total : resident;
         if (nwg >= 8 && total % 8 == 0) nwg = nwg / 8 * 8;
-        k_colstream<RL_CFG_L, C, T><<<dim3((unsigned)nwg), dim3(64 * C), lds, s>>>(p);
+        rl_launch(k_colstream<RL_CFG_L, C, T>, dim3((unsigned)nwg), dim3(64 * C), lds, s, p);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;
@@ -248,7 +263,7 @@ static hipError_t launch_row_stream_m(const void* params, hipStream_t s) {
     const long total = (long)p.frames * ((p.ny + 1) / 2);
     if (total < 1) return hipSuccess;
     const long need = (total + Q - 1) / Q;
-    k_rowstream<RL_CFG_L, Q, MODE, T><<<dim3((unsigned)(need < resident ? need : resident)), dim3(64 * Q), lds, s>>>(p);
+    rl_launch(k_rowstream<RL_CFG_L, Q, MODE, T>, dim3((unsigned)(need < resident ? need : resident)), dim3(64 * Q), lds, s, p);
     return hipGetLastError();
 }
 
@@ -282,11 +297,11 @@ template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
     if (WavePrivate<CCfg>::value && p.mode == COL_H_MULTI)
-        k_colconv<RL_CFG_L, C, COL_H_MULTI, T><<<dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s>>>(p);
+        rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T>, dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s, p);
     else if (WavePrivate<CCfg>::value && p.mode == COL_HT_SUM)
-        k_colconv<RL_CFG_L, C, COL_HT_SUM, T><<<dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s>>>(p);
+        rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T>, dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s, p);
     else if (p.mode == COL_PER_IMAGE)
-        k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T><<<dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s>>>(p);
+        rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T>, dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s, p);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -297,9 +312,9 @@ static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hip
     const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
     constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
     if (MULTI && p.V == 1)   // single view: variant without accumulator registers
-        k_rowpass<RL_CFG_L, Q, MODE, MULTI, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
+        rl_launch(k_rowpass<RL_CFG_L, Q, MODE, MULTI, T>, dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s, p);
     else
-        k_rowpass<RL_CFG_L, Q, MODE, false, T><<<dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s>>>(p);
+        rl_launch(k_rowpass<RL_CFG_L, Q, MODE, false, T>, dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s, p);
     return hipGetLastError();
 }
 

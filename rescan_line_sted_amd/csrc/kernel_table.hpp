@@ -8,6 +8,13 @@ namespace rl {
 
 enum DType { DT_F32 = 0, DT_F64 = 1 };
 
+// Timing events for the NEXT kernel launch of this thread (rl_deconv_time_cycle): the launch helpers of
+// fft_kernels.hip pass them to hipExtLaunchKernelGGL, which stamps the kernel's begin and end.
+struct LaunchTiming {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchTiming& launch_timing();   // thread local (rlsted.cpp)
+
 struct KernelTable {
     int L;            // transform length
     int T;            // threads per transform

@@ -32,6 +32,10 @@ int fail(int code, const std::string& msg) {
     last_error() = msg;
     return code;
 }
+LaunchTiming& launch_timing() {
+    thread_local LaunchTiming t;
+    return t;
+}
 bool debug_sync() {
     static const bool v = getenv("RLSTED_DEBUG_SYNC") != nullptr;
     return v;
@@ -150,7 +154,10 @@ struct rl_deconv {
         p.streams = fused_streams;
         p.timeout_us = 1000000u;
         p.flags = getenv("RLSTED_FUSED_FLAGS") ? (unsigned)atoi(getenv("RLSTED_FUSED_FLAGS")) : 0u;
-        HIP_TRY(ty->launch_fused(&p, fused_wgs, fused_acq, cur(), &fused_grid));
+        {
+            TimedScope t(this, TK_FUSED);
+            HIP_TRY(ty->launch_fused(&p, fused_wgs, fused_acq, cur(), &fused_grid));
+        }
         HIP_TRY(hipMemcpyAsync(fused_status, fused_ctrl, FW_TEAM_BASE * sizeof(unsigned), hipMemcpyDeviceToHost, cur()));
         fused_pending_frames = nf;
         if (!fused_checked) {   // first launch of this plan: look at its report before anything builds on it
@@ -177,6 +184,49 @@ struct rl_deconv {
                                     std::to_string(fused_grid) + ", registered " + std::to_string(fused_status[FW_REGISTERED]) +
                                     ", workgroups per XCD [" + xs + "] (RLSTED_FUSED=0 selects the four-launch iteration)");
     }
+
+    // ---- in-situ kernel timing (rl_deconv_time_cycle): an event pair around every launch of one whole
+    // cycle, on the stream the launch goes to, with the slice streams overlapping as in production
+    enum TimedKind { TK_COL_H = 0, TK_RATIO, TK_COL_HT, TK_UPDATE, TK_FWD, TK_INV, TK_POISSON, TK_FUSED, TK_COUNT };
+    struct TimedLaunch { int kind; hipEvent_t a, b; };
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    hipEvent_t pool_event() {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+    // usage: { TimedScope t(this, kind); launch; }.  ext: the launch goes through fft_kernels.hip's
+    // rl_launch, which stamps the kernel's own begin / end on the events (what a kernel trace shows);
+    // otherwise the events are recorded on the stream around the launch(es).
+    struct TimedScope {
+        rl_deconv* h; hipEvent_t a = nullptr, b = nullptr; int kind; bool ext;
+        TimedScope(rl_deconv* h_, int kind_, bool ext_ = true) : h(h_), kind(kind_), ext(ext_) {
+            if (!h->timing || !(a = h->pool_event()) || !(b = h->pool_event())) return;
+            if (ext) {
+                launch_timing().start = a;
+                launch_timing().stop = b;
+            } else {
+                (void)hipEventRecord(a, h->cur());
+            }
+        }
+        ~TimedScope() {
+            if (!a || !b) return;
+            if (ext) {
+                const bool used = launch_timing().start == nullptr;   // rl_launch consumed them
+                launch_timing().start = launch_timing().stop = nullptr;
+                if (!used) return;
+            } else {
+                (void)hipEventRecord(b, h->cur());
+            }
+            h->timed.push_back({kind, a, b});
+        }
+    };
 
     size_t n_img() const { return (size_t)ny * nx; }
     size_t n_spec() const { return spec_image_elems(ny, pitch); }   // complex elements of one spectrum image
@@ -205,10 +255,13 @@ struct rl_deconv {
         const unsigned gx = (unsigned)((kx + C - 1) / C);
         p.images = (int)gy;
         p.order = col_order;
-        if ((streaming & 1) && p.mode == COL_PER_IMAGE && ty->launch_col_stream)
-            HIP_TRY(ty->launch_col_stream(dtype, &p, cur()));
-        else
-            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, cur()));
+        {
+            TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
+            if ((streaming & 1) && p.mode == COL_PER_IMAGE && ty->launch_col_stream)
+                HIP_TRY(ty->launch_col_stream(dtype, &p, cur()));
+            else
+                HIP_TRY(ty->launch_col(dtype, &p, gx, gy, cur()));
+        }
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(cur());
             if (e != hipSuccess)
@@ -217,8 +270,20 @@ struct rl_deconv {
         }
         return RL_OK;
     }
+    // grid.y carries the image index of a launch: at most kMaxGridY images per launch, larger batches
+    // are launched in pieces (whole frames each) with the pointers moved on
+    static constexpr int kMaxGridY = 65535;
     int col(const void* in, void* out, int frames, ColKind kind) {
-        return dtype == RL_F32 ? col_t<float>(in, out, frames, kind) : col_t<double>(in, out, frames, kind);
+        const size_t sp = n_spec() * 2 * esize(dtype);   // bytes of one spectrum image
+        const size_t in_per = kind == COL_H ? 1 : (size_t)V, out_per = kind == COL_HT_FUSED ? 1 : (size_t)V;
+        const int step = std::max(1, kMaxGridY / V);
+        for (int f0 = 0; f0 < frames; f0 += step) {
+            const int nf = std::min(step, frames - f0);
+            const void* i = (const char*)in + (size_t)f0 * in_per * sp;
+            void* o = (char*)out + (size_t)f0 * out_per * sp;
+            RL_TRY(dtype == RL_F32 ? col_t<float>(i, o, nf, kind) : col_t<double>(i, o, nf, kind));
+        }
+        return RL_OK;
     }
     int col(const void* in, void* out, int frames, bool h_mode) { return col(in, out, frames, h_mode ? COL_H : COL_HT_VIEW); }
     template <typename T>
@@ -236,10 +301,13 @@ struct rl_deconv {
         const int Q = tx->Q[dtype];
         const unsigned pairs = (unsigned)((ny + 1) / 2);
         p.frames = (int)gy;
-        if (tx->launch_row_stream && (((streaming & 2) && mode == ROW_RATIO) || ((streaming & 4) && mode == ROW_UPDATE && views == 1)))
-            HIP_TRY(tx->launch_row_stream(dtype, mode, &p, cur()));
-        else
-            HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, cur()));
+        {
+            TimedScope t(this, mode == ROW_RATIO ? TK_RATIO : mode == ROW_UPDATE ? TK_UPDATE : mode == ROW_FWD ? TK_FWD : TK_INV);
+            if (tx->launch_row_stream && (((streaming & 2) && mode == ROW_RATIO) || ((streaming & 4) && mode == ROW_UPDATE && views == 1)))
+                HIP_TRY(tx->launch_row_stream(dtype, mode, &p, cur()));
+            else
+                HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, cur()));
+        }
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(cur());
             if (e != hipSuccess)
@@ -252,8 +320,19 @@ struct rl_deconv {
     int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
             const void* scale = nullptr, int views = -1) {
         if (views < 0) views = V;
-        return dtype == RL_F32 ? row_t<float>(mode, gy, spec_in, spec_out, src, dst, nrm, scale, views)
-                               : row_t<double>(mode, gy, spec_in, spec_out, src, dst, nrm, scale, views);
+        const size_t sp = n_spec() * 2 * esize(dtype), im = n_img() * esize(dtype);
+        const bool multi = mode == ROW_UPDATE || mode == ROW_ADJ;   // `views` input spectra per image
+        for (unsigned g0 = 0; g0 < gy; g0 += (unsigned)kMaxGridY) {
+            const unsigned ng = std::min((unsigned)kMaxGridY, gy - g0);
+            const void* si = spec_in ? (const char*)spec_in + (size_t)g0 * (multi ? (size_t)views : 1) * sp : nullptr;
+            void* so = spec_out ? (char*)spec_out + (size_t)g0 * sp : nullptr;
+            const void* sr = src ? (const char*)src + (size_t)g0 * im : nullptr;
+            void* ds = dst ? (char*)dst + (size_t)g0 * im : nullptr;
+            const void* sc = scale ? (const char*)scale + (size_t)g0 * esize(dtype) : nullptr;
+            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views)
+                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views));
+        }
+        return RL_OK;
     }
 
     // Host float64 <-> plan dtype.  The conversion (and the brightness scaling) runs on the
@@ -429,6 +508,7 @@ struct rl_deconv {
         auto simulate_slice = [&](int sl, int f0, int nf) -> int {
             RL_TRY(forward_slice(f0, nf));
             void* ws = (char*)slice_ws + (size_t)sl * slice_ws_stride;   // this slice's Poisson work list
+            TimedScope t(this, TK_POISSON, false);
             hipError_t e = aux_poisson(dtype, off(noiseless, (size_t)f0 * V * n_img()), off(meas, (size_t)f0 * V * n_img()),
                                        (unsigned)n_img(), (unsigned)(nf * V), (unsigned)(f0 * V), seed, rng_kind, ws, cur());
             if (e != hipSuccess) return fail(RL_ERR_HIP, std::string("Poisson kernels: ") + hipGetErrorString(e));
@@ -562,6 +642,7 @@ int rl_deconv_destroy(rl_deconv* h) {
                     h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
+    for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     if (h->fused_ctrl) hipFree(h->fused_ctrl);
     if (h->fused_status) hipHostFree(h->fused_status);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -648,7 +729,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     *out = nullptr;
     if (n_psf < 1 || py < 1 || px < 1 || batch < 1 || ny < 1 || nx < 1) return fail(RL_ERR_INVALID, "non-positive size");
     if (dtype != RL_F32 && dtype != RL_F64) return fail(RL_ERR_INVALID, "dtype must be RL_F32 or RL_F64");
-    if ((long long)batch * n_psf > 65535) return fail(RL_ERR_UNSUPPORTED, "batch * n_psf exceeds 65535 (grid.y)");
+    if (n_psf > rl_deconv::kMaxGridY) return fail(RL_ERR_UNSUPPORTED, "more than 65535 views");
     HIP_TRY(hipSetDevice(ctx->device));
     rl_deconv* h = new rl_deconv;
     h->ctx = ctx;
@@ -844,6 +925,48 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
 }
 
 
+int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (batch) *batch = h->B;
+    if (n_psf) *n_psf = h->V;
+    if (ny) *ny = h->ny;
+    if (nx) *nx = h->nx;
+    return RL_OK;
+}
+
+int rl_batch_run(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, double* estimates_out) {
+    if (!h || (!tasks && n_tasks > 0)) return fail(RL_ERR_INVALID, "NULL argument");
+    if (n_tasks < 0 || k_iters < 0) return fail(RL_ERR_INVALID, "negative count");
+    const int B = h->B;
+    const size_t n = h->n_img();
+    std::vector<double> stage((size_t)B * n), tb(B), est;
+    std::vector<uint64_t> seeds(B);
+    std::vector<uint32_t> ids(B);
+    if (estimates_out) est.resize((size_t)B * n);
+    for (int t0 = 0; t0 < n_tasks; t0 += B) {
+        const int nt = std::min(B, n_tasks - t0);
+        bool scaled = true;
+        for (int f = 0; f < B; ++f) {   // a short last chunk repeats its last task (the plan's batch is fixed)
+            const rl_task& t = tasks[t0 + std::min(f, nt - 1)];
+            if (!t.object) return fail(RL_ERR_INVALID, "task without an object");
+            memcpy(&stage[(size_t)f * n], t.object, n * sizeof(double));
+            tb[f] = t.total_brightness;
+            scaled = scaled && t.total_brightness > 0;
+            seeds[f] = t.seed;
+            ids[f] = t.image_id;
+        }
+        RL_TRY(rl_deconv_set_object(h, stage.data(), scaled ? tb.data() : nullptr));
+        RL_TRY(rl_deconv_simulate_keyed(h, rng_kind, seeds.data(), ids.data()));
+        RL_TRY(rl_deconv_reset_estimate(h));
+        RL_TRY(rl_deconv_iterate(h, k_iters));
+        if (estimates_out) {
+            RL_TRY(rl_deconv_get_estimate(h, est.data()));
+            memcpy(estimates_out + (size_t)t0 * n, est.data(), (size_t)nt * n * sizeof(double));
+        }
+    }
+    return RL_OK;
+}
+
 int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements, int* dtype) {
     if (!h || !ptr) return fail(RL_ERR_INVALID, "NULL argument");
     void* p = nullptr;
@@ -858,6 +981,37 @@ int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements
     *ptr = p;
     if (n_elements) *n_elements = n;
     if (dtype) *dtype = h->dtype;
+    return RL_OK;
+}
+
+int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, double* avg_ms, double* launches, double* frames_per_launch) {
+    if (!h || !avg_ms) return fail(RL_ERR_INVALID, "NULL argument");
+    if (!h->have_obj) return fail(RL_ERR_STATE, "rl_deconv_set_object has not been called");
+    if (k < 0) return fail(RL_ERR_INVALID, "k < 0");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    h->timed.clear();
+    h->events_used = 0;
+    h->timing = true;
+    int rc = h->run_cycle(k, rng_kind, seed);
+    h->timing = false;
+    hipError_t e = hipDeviceSynchronize();
+    RL_TRY(rc);
+    HIP_TRY(e);
+    h->have_meas = true;
+    RL_TRY(h->fused_check());
+    double sum[rl_deconv::TK_COUNT] = {0}, cnt[rl_deconv::TK_COUNT] = {0};
+    for (const auto& t : h->timed) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+        sum[t.kind] += ms;
+        cnt[t.kind] += 1;
+    }
+    for (int i = 0; i < rl_deconv::TK_COUNT; ++i) {
+        avg_ms[i] = cnt[i] > 0 ? sum[i] / cnt[i] : 0.0;
+        if (launches) launches[i] = cnt[i];
+    }
+    if (frames_per_launch) *frames_per_launch = (double)((h->fused_available() && k > 0) ? h->B : h->chunk_frames());
     return RL_OK;
 }
 

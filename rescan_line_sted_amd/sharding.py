@@ -3,10 +3,18 @@
 Every (test object x dose x scan mode x noise seed) task is independent
 (separate Deconvolver objects in the reference, line_sted_figure_2.py:39-56),
 so the task list is partitioned over ranks -- one process per GPU -- with no
-collective in the data path and ONE gather of the final estimates at the end
-(RCCL over xGMI when the process group's backend is 'nccl', gloo on CPU).
-torch.distributed is used purely as the communication plumbing.
+collective in the data path and ONE gather of the final estimates at the end.
+
+The transport is RCCL over xGMI through the C ABI (`rl_comm_*`, `rl_gather*` of
+include/rlsted.h): `RcclComm`.  Anything with the same four members --
+`rank`, `world`, `barrier()`, `allreduce_max(x)`, `gather(array, counts, root)` --
+can stand in for it (the CPU tests use a gloo-backed one, tests/comm_gloo.py).
 """
+import ctypes
+import os
+import tempfile
+import time
+
 import numpy as np
 
 
@@ -32,7 +40,7 @@ def partition(costs, world_size):
 
 class DeviceArray:
     """Exposes a device buffer owned by a DeconvPlan through
-    __cuda_array_interface__ so torch can wrap it without a copy."""
+    __cuda_array_interface__ so other libraries can wrap it without a copy."""
 
     def __init__(self, ptr, shape, typestr, owner):
         self.owner = owner
@@ -40,30 +48,110 @@ class DeviceArray:
                                          'version': 2, 'strides': None}
 
 
-def gather_to_root(local, counts, dist, root=0):
-    """Gather per-rank result stacks on `root`.
+def rendezvous_path():
+    """Where rank 0 leaves the RCCL unique id for the other ranks of this launch: all ranks of one
+    launcher share a parent process and a MASTER_PORT."""
+    tag = '%d_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
+    return os.path.join(tempfile.gettempdir(), 'rlsted_rccl_%s.id' % tag)
 
-    local  : numpy array or torch tensor (n_local, ...) of this rank's results
-    counts : number of results on every rank (len == world size)
-    dist   : an initialised torch.distributed module (any backend)
-    Returns the concatenated stack on root (numpy if `local` was numpy), None elsewhere.
-    """
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    was_numpy = isinstance(local, np.ndarray)
-    t = torch.from_numpy(np.ascontiguousarray(local)) if was_numpy else local.contiguous()
-    if dist.get_backend() == 'nccl' and not t.is_cuda:
-        t = t.cuda()
-    nmax = int(max(counts))
-    item = tuple(t.shape[1:])
-    pad = torch.zeros((nmax,) + item, dtype=t.dtype, device=t.device)
-    pad[:t.shape[0]] = t
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
-    dist.gather(pad, bufs, dst=root)
-    if rank != root:
-        return None
-    out = torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
-    return out.cpu().numpy() if was_numpy else out
+
+def exchange_unique_id(rank, make_id, path=None, timeout=300.0, nbytes=128):
+    """Rank 0 creates the id and publishes it atomically in a file; the others wait for the file."""
+    path = path or rendezvous_path()
+    if rank == 0:
+        blob = make_id()
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(blob)
+        os.replace(tmp, path)
+        return blob
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                blob = f.read()
+            if len(blob) == nbytes:
+                return blob
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError('no RCCL unique id at %s after %.0f s' % (path, timeout))
+        time.sleep(0.01)
+
+
+class RcclComm:
+    """rl_comm: one per process, created collectively by all ranks."""
+
+    def __init__(self, rank, world, device=0, path=None):
+        from . import _lib
+        self._lib = _lib
+        self.rank, self.world = int(rank), int(world)
+        self.ctx = _lib.Context.get(device)
+
+        def make_id():
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(_lib.lib.rl_comm_unique_id(buf))
+            return buf.raw
+        self._path = path or rendezvous_path()
+        blob = exchange_unique_id(self.rank, make_id, self._path)
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib.rl_comm_create(self.ctx.handle, self.rank, self.world, ctypes.c_char_p(blob),
+                                           ctypes.byref(self.handle)))
+        self.barrier()              # every rank has read the id
+        if self.rank == 0:
+            try:
+                os.remove(self._path)
+            except OSError:
+                pass
+
+    @classmethod
+    def from_env(cls, device=None):
+        """Ranks as torch.distributed.run (or any launcher) exports them: RANK, WORLD_SIZE, LOCAL_RANK."""
+        rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+        return cls(rank, world, int(os.environ.get('LOCAL_RANK', '0')) if device is None else device)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.lib.rl_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def barrier(self):
+        self._lib.check(self._lib.lib.rl_comm_barrier(self.handle))
+
+    def allreduce_max(self, x):
+        v = ctypes.c_double(float(x))
+        self._lib.check(self._lib.lib.rl_comm_allreduce_max(self.handle, ctypes.byref(v)))
+        return v.value
+
+    def gather(self, local, counts, root=0):
+        """Host arrays: rank r contributes counts[r] items (local.shape[0] == counts[rank]); returns the
+        rank-major concatenation on root (float64), None elsewhere."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        item = int(np.prod(local.shape[1:], dtype=np.int64)) if local.ndim > 1 else 1
+        sizes = (ctypes.c_size_t * self.world)(*[int(c) * item for c in counts])
+        out = np.empty((int(sum(counts)),) + tuple(local.shape[1:]), dtype=np.float64) if self.rank == root else None
+        self._lib.check(self._lib.lib.rl_comm_gather_host(
+            self.handle, self._lib.ptr(local) if local.size else None, sizes, int(root),
+            self._lib.ptr(out) if out is not None and out.size else None))
+        return out
+
+    def gather_plan(self, plan, counts, which='estimate', root=0, to_host=True):
+        """The first counts[r] frames of every rank's plan buffer, straight from device memory (rl_gather).
+        to_host=False leaves the result on the root's device and returns (pointer, elements, dtype)."""
+        cs = (ctypes.c_int * self.world)(*[int(c) for c in counts])
+        idx = plan.BUFFERS[which]
+        if not to_host:
+            p, n, dt = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int()
+            self._lib.check(self._lib.lib.rl_gather_device(self.handle, plan.handle, idx, int(root), cs, ctypes.byref(p),
+                                                           ctypes.byref(n), ctypes.byref(dt)))
+            return (p.value, n.value, dt.value)
+        shape = (plan.ny, plan.nx) if idx in (0, 3) else (plan.V, plan.ny, plan.nx)
+        out = np.empty((int(sum(counts)),) + shape, dtype=np.float64) if self.rank == root else None
+        self._lib.check(self._lib.lib.rl_gather(self.handle, plan.handle, idx, int(root), cs,
+                                                self._lib.ptr(out) if out is not None else None))
+        return out
 
 
 def unshard(shards, gathered):
@@ -74,25 +162,17 @@ def unshard(shards, gathered):
     return out
 
 
-def run_sharded(tasks, costs, run_local, dist=None):
+def run_sharded(tasks, costs, run_local, comm=None):
     """Partition `tasks`, run this rank's share with run_local(list_of_tasks) ->
     array (n_local, ...), gather on rank 0 and return results in task order
-    (rank 0) or None (other ranks).  With dist=None runs everything locally."""
-    if dist is None:
+    (rank 0) or None (other ranks).  With comm=None runs everything locally."""
+    if comm is None:
         return np.asarray(run_local(list(tasks)))
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = comm.world, comm.rank
     shards = partition(costs, world)
     mine = [tasks[i] for i in shards[rank]]
-    local = np.asarray(run_local(mine)) if mine else None
-    if local is None:       # a rank without tasks still joins the gather with an empty stack
-        import torch
-        shape = [None]
-        dist.broadcast_object_list(shape, src=next(r for r in range(world) if shards[r]))
-        local = np.zeros((0,) + tuple(shape[0]), dtype=np.float64)
-    else:
-        import torch
-        first = next(r for r in range(world) if shards[r])
-        shape = [tuple(local.shape[1:])] if rank == first else [None]
-        dist.broadcast_object_list(shape, src=first)
-    gathered = gather_to_root(local, [len(s) for s in shards], dist)
+    # a rank without tasks joins the gather with an empty stack (the greedy partition fills rank 0
+    # first, so the root always knows the item shape when there is any task at all)
+    local = np.asarray(run_local(mine), dtype=np.float64) if mine else np.zeros((0,), dtype=np.float64)
+    gathered = comm.gather(local, [len(s) for s in shards], 0)
     return unshard(shards, gathered) if rank == 0 else None

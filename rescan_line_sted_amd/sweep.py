@@ -45,10 +45,8 @@ def run_tasks(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype
             part = idxs[start:start + max_frames_per_plan]
             frames = np.stack([np.asarray(objects[tasks[i][0]], dtype=np.float64).reshape(shape) for i in part])
             plan = DeconvPlan(psf_sets[p], len(part), shape[0], shape[1], dtype=dtype, device=device)
-            plan.set_object(frames, total_brightness)
-            plan.simulate_keyed([tasks[i][2] for i in part], [ids[tasks[i][0]] for i in part], rng=RNG_PHILOX)
-            plan.iterate(iterations)
-            est = plan.estimate()
+            est = plan.batch_run(frames, total_brightness, [tasks[i][2] for i in part], [ids[tasks[i][0]] for i in part],
+                                 iterations, rng=RNG_PHILOX)      # rl_batch_run of the C ABI
             for k, i in enumerate(part):
                 out[i] = est[k]
             del plan
@@ -65,9 +63,9 @@ def pad_stack(images, shape):
 
 
 def figure_2_sweep(objects, psf_sets, seeds, iterations, total_brightness=5e10, dtype='f32',
-                   device=0, dist=None):
-    """The sweep, sharded over the ranks of `dist` (an initialised torch.distributed
-    module) when given.  Returns (tasks, estimates) on rank 0 and (tasks, None) elsewhere;
+                   device=0, comm=None):
+    """The sweep, sharded over the ranks of `comm` (sharding.RcclComm, or anything with its
+    interface) when given.  Returns (tasks, estimates) on rank 0 and (tasks, None) elsewhere;
     estimates is an array (n_tasks, ny, nx) when all objects share a shape, otherwise a list of
     (ny, nx) arrays in task order (the figure's test objects are 128x128 and 160x160: the
     single gather then carries frames zero-padded to the largest shape, cropped on rank 0)."""
@@ -78,7 +76,7 @@ def figure_2_sweep(objects, psf_sets, seeds, iterations, total_brightness=5e10, 
 
     def run_local(mine):
         return pad_stack(run_tasks(mine, objects, psf_sets, iterations, total_brightness, dtype, device), big)
-    padded = sharding.run_sharded(tasks, costs, run_local, dist)
+    padded = sharding.run_sharded(tasks, costs, run_local, comm)
     if padded is None:
         return tasks, None
     if len(shapes) == 1:

@@ -1,0 +1,117 @@
+"""Multi-GPU plumbing and the batch entry points of the C ABI on one MI355X: the RCCL communicator at
+world size 1 (a world of 2 cannot share one GPU: RCCL refuses duplicate devices; the N > 1 control flow
+is covered on CPU in test_sharding.py / test_bench_cli.py), rl_batch_run, the in-situ cycle timing, the
+fused Richardson-Lucy kernel, and launches of more than 65535 images."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import max_rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from rescan_line_sted_amd import _lib
+    assert _lib.device_count() >= 1, 'no GPU visible'
+    return _lib
+
+
+@pytest.fixture(scope='module')
+def small(golden):
+    psf = [golden('g8_fig2_psfs')['1p5x_lr/point_sted_psf'][0]]
+    obj = golden('objects')['rings'].astype(np.float64)[0]
+    return psf, obj
+
+
+def test_rccl_comm_world_1_gather(lib, small, tmp_path):
+    from rescan_line_sted_amd import sharding
+    psf, obj = small
+    comm = sharding.RcclComm(0, 1, device=0, path=str(tmp_path / 'id'))
+    assert (comm.rank, comm.world) == (0, 1) and not os.path.exists(str(tmp_path / 'id'))
+    assert comm.allreduce_max(3.5) == 3.5
+    comm.barrier()
+    plan = lib.DeconvPlan(psf, 3, 128, 128, dtype='f32')
+    plan.set_object(np.stack([obj, 2 * obj, 3 * obj]), 5e10)
+    plan.simulate(seed=3)
+    plan.iterate(3)
+    got = comm.gather_plan(plan, [2], 'estimate')
+    assert np.array_equal(got, plan.estimate()[:2])
+    meas = comm.gather_plan(plan, [3], 'measurement')
+    assert np.array_equal(meas, plan.measurement())
+    ptr, n, dt = comm.gather_plan(plan, [3], 'estimate', to_host=False)
+    assert ptr and n == 3 * 128 * 128 and dt == lib.RL_F32
+    x = np.arange(24, dtype=np.float64).reshape(4, 3, 2)
+    assert np.array_equal(comm.gather(x, [4]), x)
+    res = sharding.run_sharded([5, 6, 7], [1.0, 2.0, 3.0], lambda ts: np.array([[t, 2.0 * t] for t in ts]), comm)
+    assert np.array_equal(res, [[5, 10], [6, 12], [7, 14]])
+    comm.close()
+
+
+def test_batch_run_equals_the_calls_it_is_made_of(lib, small):
+    psf, obj = small
+    objs = np.stack([obj * (1 + 0.1 * i) for i in range(5)])
+    seeds, ids = np.array([11, 12, 13, 14, 15], dtype=np.uint64), np.array([0, 1, 2, 3, 4], dtype=np.uint32)
+    plan = lib.DeconvPlan(psf, 2, 128, 128, dtype='f32')
+    est = plan.batch_run(objs, 5e10, seeds, ids, 4)
+    assert est.shape == (5, 128, 128)
+    single = lib.DeconvPlan(psf, 1, 128, 128, dtype='f32')
+    for i in range(5):      # a task's result depends on the task only, not on its chunk
+        single.set_object(objs[i], 5e10)
+        single.simulate_keyed(seeds[i], ids[i])
+        single.reset_estimate()
+        single.iterate(4)
+        assert np.array_equal(single.estimate()[0], est[i]), i
+
+
+def test_time_cycle_brackets_every_launch(lib, small):
+    psf, obj = small
+    plan = lib.DeconvPlan(psf, 8, 128, 128, dtype='f32')
+    plan.set_object(np.broadcast_to(obj, (8, 128, 128)), 5e10)
+    kt, fpl = plan.time_cycle(5, seed=1)
+    assert fpl >= 1
+    for name in ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'rowpass_INV', 'poisson'):
+        assert name in kt and kt[name][0] > 0 and kt[name][1] >= 1, (name, kt)
+    slices = kt['poisson'][1]
+    assert kt['rowpass_RATIO'][1] == 5 * slices and kt['colconv_H'][1] == 6 * slices
+    # the timed cycle leaves what an untimed one leaves
+    a = plan.estimate()
+    plan.bench_cycles(5, 1, seed=1)
+    assert np.array_equal(a, plan.estimate())
+
+
+def test_fused_rl_kernel_matches_the_four_launch_iteration(lib, golden, monkeypatch):
+    """RLSTED_FUSED=1: one persistent launch for all iterations (teams of workgroups per XCD).  The item
+    code is the four-launch path's; the two are separate compilations of it (fused-multiply-add
+    contraction may differ), so agreement is to rounding, not bit for bit."""
+    psf = [golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'][0]]
+    obj = np.kron(golden('objects')['astronaut'].astype(np.float64), np.ones((1, 4, 4)))[0]
+    B = 24
+    est = {}
+    for fused in ('0', '1'):
+        monkeypatch.setenv('RLSTED_FUSED', fused)
+        plan = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
+        plan.set_object(np.broadcast_to(obj, (B, 512, 512)), 5e10 * 16)
+        plan.simulate(seed=5)
+        plan.iterate(7)
+        plan.iterate(3)          # continues from the current estimate
+        est[fused] = plan.estimate()
+        del plan
+    assert np.isfinite(est['1']).all()
+    assert max_rel(est['1'], est['0']) < 3e-6
+
+
+def test_more_images_than_grid_y(lib):
+    rng = np.random.default_rng(0)
+    psf = [rng.random((1, 5, 5))]
+    B = 66000
+    x = rng.random((B, 12, 12))
+    plan = lib.DeconvPlan(psf, B, 12, 12, dtype='f32')
+    y = plan.forward(x)
+    pick = [0, 1, 65534, 65535, 65536, B - 1]
+    ref = lib.DeconvPlan(psf, len(pick), 12, 12, dtype='f32')
+    assert np.array_equal(ref.forward(x[pick]), y[pick])
+    z = plan.adjoint(y)
+    assert np.array_equal(ref.adjoint(y[pick]), z[pick])

@@ -1,11 +1,15 @@
-"""N > 1 path on CPU: cost-weighted partition + gather, world_size 2, gloo."""
+"""N > 1 path on CPU: cost-weighted partition + gather, world_size 2, gloo (tests/comm_gloo.py stands in
+for the RCCL communicator of the C ABI), and the file rendezvous of the RCCL unique id."""
 import os
 import socket
+
+import sys
 
 import numpy as np
 import pytest
 
-from rescan_line_sted_amd import sharding
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # comm_gloo, also in the spawned workers
+from rescan_line_sted_amd import sharding  # noqa: E402
 
 
 def test_partition_is_balanced_and_complete():
@@ -41,7 +45,8 @@ def _worker(rank, world, port, n_tasks, out_path):
 
     def run_local(mine):        # stand-in for the device plan: result encodes the task id
         return np.stack([np.full((4, 6), float(t)) + np.arange(6) for t in mine])
-    res = sharding.run_sharded(tasks, costs, run_local, dist)
+    from comm_gloo import GlooComm
+    res = sharding.run_sharded(tasks, costs, run_local, GlooComm(dist))
     if rank == 0:
         np.save(out_path, res)
     else:
@@ -74,7 +79,8 @@ def _sweep_worker(rank, world, port, out_path):
         ids = sweep.object_ids(objects_)
         return [np.full(objects_[o].shape[-2:], 100.0 * ids[o] + 10.0 * len(psf_sets_[p]) + s) for o, p, s in tasks]
     sweep.run_tasks = fake_run_tasks
-    tasks, est = sweep.figure_2_sweep(objects, psf_sets, seeds=(0, 1, 2), iterations=5, dist=dist)
+    from comm_gloo import GlooComm
+    tasks, est = sweep.figure_2_sweep(objects, psf_sets, seeds=(0, 1, 2), iterations=5, comm=GlooComm(dist))
     if rank == 0:
         ids = sweep.object_ids(objects)
         assert len(est) == len(tasks) == 18
@@ -95,3 +101,26 @@ def test_mixed_shape_sweep_world_size_2_gloo(tmp_path):
     out = str(tmp_path / 'ok.txt')
     mp.spawn(_sweep_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == 'ok'
+
+
+def test_product_sharding_is_torch_free():
+    src = open(sharding.__file__).read()
+    assert 'import torch' not in src and 'torch.' not in src.replace('torch.distributed.run', '')
+
+
+def _id_worker(rank, path, q):
+    q.put((rank, sharding.exchange_unique_id(rank, lambda: bytes(range(128)), path=path, timeout=30)))
+
+
+def test_unique_id_rendezvous_by_file(tmp_path):
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    path = str(tmp_path / 'id')
+    procs = [ctx.Process(target=_id_worker, args=(r, path, q)) for r in (1, 2, 0)]   # readers start first
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join()
+    assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
