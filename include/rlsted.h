@@ -215,6 +215,33 @@ int rl_fft2_magnitude(rl_ctx* ctx, const double* x, int n_img, int ny, int nx, d
 int rl_spline_sample(rl_ctx* ctx, const double* image, int ny, int nx, const double* ys, const double* xs, int n,
                      double* out);
 
+/* ---- line_sted_figure_3.py: the scan-position-by-scan-position imaging simulator (:76-273) ----
+ * rl_rotate_image: `rotate` (:382-391) for one [ny][nx] plane -- scipy.ndimage.rotate(order 3,
+ * mode 'nearest', reshape=False) about the centre; clip != 0 clips to [0, 1.1 * max(in)].  Host in / out. */
+int rl_rotate_image(rl_ctx* ctx, const double* in, double* out, int ny, int nx, double degrees, int clip);
+
+/* One orientation's scan (:172-239), all scan positions in one call, batched on the device.
+ * rot_obj, centered_exc: [ny][nx] (the padded, rotated object :169; the blurred excitation :139).
+ * positions: [n_pos][2] = (shift_y, shift_x) (:112-137).  display: ascending indices of the positions
+ * whose detector images are wanted (the frames the reference renders, :258-263).
+ * pos_scalars [n_pos][4] = { glow.max(), inst_detector_sig.max(), cum_detector_sig.max(),
+ *   inst_detector_sig.sum() } per position (:252-256; the sum is descan_point's reconstruction value :200).
+ * pos_values: descan_line [n_pos][nx] = inst_detector_sig.sum(axis=1) (:192); nondescan_multipoint
+ *   [n_pos][ceil(n_y/exc_sep) * ceil(n_x/exc_sep)] = the region sums (:213-220), y major; else unused.
+ * display_out [n_display][2][ny][nx] = inst_detector_sig, cum_detector_sig of the display positions.
+ * cum_final [ny][nx]: rescan_line's accumulated detector image (:234), else unused.              */
+typedef struct rl_fig3_params {
+    int imaging_type;    /* 0 descan_point, 1 nondescan_multipoint, 2 descan_line, 3 rescan_line */
+    int ny, nx;          /* padded shape */
+    int n_y, n_x, pad;   /* object shape and padding (:106-107) */
+    int step, exc_sep;   /* scan step (:102); spot separation (:131, multipoint) */
+    double psf_sigma;    /* detection blur (:100) */
+    double rescan_scale; /* 1 / (R^2 + 1) (:229), rescan_line */
+} rl_fig3_params;
+int rl_fig3_scan(rl_ctx* ctx, const rl_fig3_params* p, const double* rot_obj, const double* centered_exc,
+                 const int* positions, int n_pos, const int* display, int n_display, double* pos_scalars,
+                 double* pos_values, double* display_out, double* cum_final);
+
 /* Per-kernel device time: launches each kernel of the RL iteration `reps`
  * times back to back between two hipEvents on the plan's stream and returns
  * the average milliseconds per launch in avg_ms[0..5] = { column pass (H),

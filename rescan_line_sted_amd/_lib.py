@@ -58,6 +58,8 @@ PROTOTYPES = {
     'rl_gather': (_i, [_vp, _vp, _i, _i, _c.POINTER(_i), _dp]),
     'rl_gather_device': (_i, [_vp, _vp, _i, _i, _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
     'rl_comm_gather_host': (_i, [_vp, _dp, _c.POINTER(_c.c_size_t), _i, _dp]),
+    'rl_rotate_image': (_i, [_vp, _dp, _dp, _i, _i, _c.c_double, _i]),
+    'rl_fig3_scan': (_i, [_vp, _vp, _dp, _dp, _c.POINTER(_i), _i, _c.POINTER(_i), _i, _dp, _dp, _dp, _dp]),
     'rl_gauss_fit': (_i, [_dp, _i, _dp, _c.POINTER(_i)]),
     'rl_gaussian_filter': (_i, [_vp, _dp, _dp, _i, _i, _i, _dp, _c.c_double]),
     'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
