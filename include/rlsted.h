@@ -88,6 +88,10 @@ int rl_deconv_set_measurement(rl_deconv* h, const double* noisy);
 /* iterate (:520-531) K times; the first call starts from estimate = 1.       */
 int rl_deconv_iterate(rl_deconv* h, int k);
 int rl_deconv_reset_estimate(rl_deconv* h);
+/* Deconvolver.estimate is a plain attribute in the reference (:522,530): assigning to it, or replacing
+ * the measurement after some iterations (create_data_from_object called again, :496-512), continues
+ * from that estimate.  Uploads estimate [batch][ny][nx]; the next rl_deconv_iterate continues from it. */
+int rl_deconv_set_estimate(rl_deconv* h, const double* estimate);
 
 int rl_deconv_get_object(rl_deconv* h, double* out);        /* [batch][ny][nx]        */
 int rl_deconv_get_noiseless(rl_deconv* h, double* out);     /* [batch][n_psf][ny][nx] */

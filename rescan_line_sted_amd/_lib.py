@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_lib', 'librlsted.so')
+LIB_PATH = os.environ.get('RLSTED_LIB') or os.path.join(_HERE, '_lib', 'librlsted.so')   # RLSTED_LIB: a build variant (development)
 
 RL_F32, RL_F64 = 0, 1
 RNG_NONE, RNG_PHILOX = 0, 1
@@ -35,6 +35,7 @@ PROTOTYPES = {
     'rl_deconv_set_measurement': (_i, [_vp, _dp]),
     'rl_deconv_iterate': (_i, [_vp, _i]),
     'rl_deconv_reset_estimate': (_i, [_vp]),
+    'rl_deconv_set_estimate': (_i, [_vp, _dp]),
     'rl_deconv_get_object': (_i, [_vp, _dp]),
     'rl_deconv_get_noiseless': (_i, [_vp, _dp]),
     'rl_deconv_get_measurement': (_i, [_vp, _dp]),
@@ -176,6 +177,10 @@ class DeconvPlan:
 
     def reset_estimate(self):
         check(lib.rl_deconv_reset_estimate(self.handle))
+
+    def set_estimate(self, est):
+        est = as_f64(est).reshape(self.B, self.ny, self.nx)
+        check(lib.rl_deconv_set_estimate(self.handle, ptr(est)))
 
     def _get(self, fn, shape):
         out = np.empty(shape, dtype=np.float64)

@@ -27,8 +27,11 @@ namespace rl {
 // a / b.  float: hardware reciprocal (v_rcp_f32, <= 1 ulp) times a -- the f32 plans
 // are specified to 1e-5, an IEEE-exact quotient costs ~10 instructions per element;
 // double: exact division.  On the host (emulator) both are plain divisions.
+#ifndef RL_EXACT_DIV
+#define RL_EXACT_DIV 0
+#endif
 RL_HD float rl_div(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !RL_EXACT_DIV
     return a * __builtin_amdgcn_rcpf(b);
 #else
     return a / b;

@@ -151,6 +151,10 @@ struct FftCfg {
         return p;
     }
     static_assert(product() == L_, "radices must multiply to L");
+    // A transform on fewer than 64 threads must tile the wavefront exactly: with T = 48 a wave holds lanes of
+    // two transforms in different butterfly rounds (a (4,6,8) x 48 geometry for L = 192 produced wrong rows on
+    // hardware in lanes 32-47 while the host emulation, which has no wavefronts, passed).  Not supported.
+    static_assert(T_ >= 64 || 64 % T_ == 0, "a sub-wave transform must use a thread count that divides 64");
 };
 
 template <class Cfg, bool INV, int P>

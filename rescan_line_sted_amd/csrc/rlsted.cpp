@@ -505,6 +505,10 @@ struct rl_deconv {
             slice_ws_stride = stride;
         }
         int rc = RL_OK;
+        struct ActiveGuard {   // whatever path leaves this function, the launch helpers are back on the context's stream
+            hipStream_t& a;
+            ~ActiveGuard() { a = nullptr; }
+        } active_guard{active};
         auto simulate_slice = [&](int sl, int f0, int nf) -> int {
             RL_TRY(forward_slice(f0, nf));
             void* ws = (char*)slice_ws + (size_t)sl * slice_ws_stride;   // this slice's Poisson work list
@@ -827,6 +831,15 @@ int rl_deconv_set_measurement(rl_deconv* h, const double* noisy) {
     RL_TRY(h->upload(noisy, h->meas, (size_t)h->B * h->V * h->n_img()));
     h->have_meas = true;
     h->est_ready = false;
+    return RL_OK;
+}
+
+int rl_deconv_set_estimate(rl_deconv* h, const double* estimate) {
+    if (!h || !estimate) return fail(RL_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    RL_TRY(h->upload(estimate, h->est, (size_t)h->B * h->n_img()));
+    h->est_ready = true;
+    h->spec_valid = false;   // the next iterate rebuilds rowFFT(estimate)
     return RL_OK;
 }
 

@@ -62,24 +62,47 @@ class Deconvolver:
                 raise NotImplementedError(
                     'device path supports 2-D PSFs of shape (1, py, px); got %s' % (np.shape(p),))
         self._plan = None
+        self._aux_plans = {}            # H / H_t on shapes other than the data's (the RL state stays untouched)
         self._estimate = None
-        self._estimate_stale = False
+        self._estimate_stale = False    # the device holds a newer estimate than self._estimate
+        self._estimate_push = False     # self._estimate must go to the device before the next iteration
         return None
 
     # ---- device plan management -------------------------------------------
     def _plan_for(self, shape):
+        """The plan that holds the data (object, measurement, estimate)."""
         nz, ny, nx = shape
         p = self._plan
         if p is None or (p.B, p.ny, p.nx) != (nz, ny, nx):
+            if p is not None and self._estimate_stale:      # keep what the old plan computed
+                self._estimate, self._estimate_stale = p.estimate(), False
             self._plan = DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)
+            self._measurement_on_device = False             # the host copy is pushed again when needed
+            self._estimate_push = self._estimate is not None and np.shape(self._estimate) == (nz, ny, nx)
             if hasattr(self, 'H_t_normalization'):
                 del self.H_t_normalization
         return self._plan
+
+    def _operator_plan(self, shape):
+        """H / H_t accept arrays of any shape in the reference (ref:567-594) without touching the
+        deconvolver's state: other shapes than the data's get a plan of their own."""
+        nz, ny, nx = shape
+        p = self._plan
+        if p is None:
+            return self._plan_for(shape)
+        if (p.B, p.ny, p.nx) == (nz, ny, nx):
+            return p
+        key = (nz, ny, nx)
+        if key not in self._aux_plans:
+            self._aux_plans = {key: DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)}
+        return self._aux_plans[key]
 
     # ---- data ---------------------------------------------------------------
     def create_data_from_object(self, obj, total_brightness=None, random_seed=None):
         assert len(obj.shape) == 3                      # ref:502
         assert obj.dtype == np.float64                  # ref:503
+        if self._estimate_stale and self._plan is not None:   # fetch before the plan's measurement changes
+            self._estimate, self._estimate_stale = self._plan.estimate(), False
         plan = self._plan_for(obj.shape)
         plan.set_object(obj, None if total_brightness is None
                         else self._brightness(obj, total_brightness))
@@ -99,6 +122,8 @@ class Deconvolver:
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
         self._measurement_on_device = True
+        if self.num_iterations > 0 and self._estimate is not None:   # the reference keeps self.estimate (ref:521)
+            self._estimate_push = np.shape(self._estimate) == (plan.B, plan.ny, plan.nx)
         return None
 
     @staticmethod
@@ -122,19 +147,39 @@ class Deconvolver:
     # ---- Richardson-Lucy -----------------------------------------------------
     def _push_measurement(self):
         m = self.noisy_measurement
-        m = [np.asarray(v) for v in m] if isinstance(m, (list, tuple)) else [np.asarray(m)]
+        if isinstance(m, (list, tuple)):
+            m = [np.asarray(v) for v in m]
+        else:
+            # A stack loaded from noisy_measurement.tif: record_data writes the views one after the
+            # other along axis 0 (ref:562-564), so with V PSFs axis 0 is (view, slice).
+            m, V = np.asarray(m), len(self.psfs)
+            if m.shape[0] % V != 0:
+                raise ValueError('measurement stack of %d slices for %d PSFs' % (m.shape[0], V))
+            m = list(m.reshape((V, m.shape[0] // V) + m.shape[1:]))
+        keep = None
+        if self.num_iterations > 0 and (self._estimate_stale or self._estimate is not None):
+            keep = self.estimate                            # new data, same estimate (ref:521)
         plan = self._plan_for(m[0].shape)
         plan.set_measurement(np.stack(m, axis=1))
         self._measurement_on_device = True
+        if keep is not None and np.shape(keep) == (plan.B, plan.ny, plan.nx):
+            self._estimate, self._estimate_push = keep, True
         return plan
+
+    def _sync_estimate(self, plan):
+        if self._estimate_push:
+            plan.set_estimate(self._estimate)
+            self._estimate_push = False
 
     def iterate(self):
         """ref:520-531: estimate *= H_t(measurement / H(estimate))."""
         if not getattr(self, '_measurement_on_device', False):
             self._push_measurement()
         plan = self._plan
-        if self.num_iterations == 0:
+        if self.num_iterations == 0:                      # ref:521-522: always from ones
             plan.reset_estimate()
+            self._estimate_push = False
+        self._sync_estimate(plan)
         self.num_iterations += 1
         plan.iterate(1)
         self._estimate_stale = True
@@ -146,6 +191,8 @@ class Deconvolver:
             self._push_measurement()
         if self.num_iterations == 0:
             self._plan.reset_estimate()
+            self._estimate_push = False
+        self._sync_estimate(self._plan)
         self.num_iterations += k
         self._plan.iterate(k)
         self._estimate_stale = True
@@ -159,18 +206,26 @@ class Deconvolver:
             raise AttributeError('estimate')          # like the reference before iterate()
         return self._estimate
 
+    @estimate.setter
+    def estimate(self, value):
+        """A plain attribute in the reference: after the first iteration `d.estimate = x` makes the next
+        iterate() continue from x (the first iterate() always starts from ones, ref:521-522)."""
+        self._estimate = np.array(value, dtype=np.float64)
+        self._estimate_stale = False
+        self._estimate_push = True
+
     # ---- operators -------------------------------------------------------------
     def H(self, x):
         """ref:567-577: list, one blurred (clamped >= 0) image stack per PSF."""
         x = np.asarray(x, dtype=np.float64)
-        plan = self._plan_for(x.shape)
+        plan = self._operator_plan(x.shape)
         out = plan.forward(x)
         return [np.ascontiguousarray(out[:, v]) for v in range(plan.V)]
 
     def H_t(self, y, normalize=True):
         """ref:579-594."""
         y = [np.asarray(v, dtype=np.float64) for v in y]
-        plan = self._plan_for(y[0].shape)
+        plan = self._operator_plan(y[0].shape)
         if normalize and not hasattr(self, 'H_t_normalization'):
             self.H_t_normalization = plan.normalization().reshape(1, plan.ny, plan.nx) * np.ones((plan.B, 1, 1))
         return plan.adjoint(np.stack(y, axis=1), normalize=normalize)

@@ -1,0 +1,90 @@
+"""State semantics of the Deconvolver mirror where the reference's object is just a bag of attributes
+(ADVICE r01): assigning to `estimate`, new data after some iterations, H / H_t on other shapes, and the
+multi-view record_data -> load_data_from_tif round trip."""
+import numpy as np
+import pytest
+
+from conftest import max_rel
+from oracle import line_sted_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def st():
+    from rescan_line_sted_amd import _lib, line_sted_tools
+    assert _lib.device_count() >= 1, 'no GPU visible'
+    return line_sted_tools
+
+
+@pytest.fixture(scope='module')
+def views(golden):
+    return [p[None] for p in golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][:2, 0]]
+
+
+@pytest.fixture(scope='module')
+def obj(golden):
+    return golden('objects')['rings'].astype(np.float64)
+
+
+def test_assigning_the_estimate_continues_from_it(st, views, obj, tmp_path):
+    d = st.Deconvolver(views, str(tmp_path) + '/', verbose=False)
+    d.create_data_from_object(obj, 5e10, random_seed=3)
+    o = orc.Deconvolver(views)
+    o.create_data_from_object(obj, 5e10, noisy_measurement=d.noisy_measurement)
+    d.estimate = 7 * np.ones_like(obj)      # before the first iteration: overwritten by ones (ref:521-522)
+    for _ in range(2):
+        d.iterate()
+        o.iterate()
+    assert max_rel(d.estimate, o.estimate) < 1e-10
+    d.estimate = 2 * d.estimate
+    o.estimate = 2 * o.estimate
+    d.iterate()
+    o.iterate()
+    assert max_rel(d.estimate, o.estimate) < 1e-10
+
+
+def test_new_data_keeps_the_estimate(st, views, obj, tmp_path):
+    d = st.Deconvolver(views, str(tmp_path) + '/', verbose=False)
+    d.create_data_from_object(obj, 5e10, random_seed=3)
+    o = orc.Deconvolver(views)
+    o.create_data_from_object(obj, 5e10, noisy_measurement=d.noisy_measurement)
+    for _ in range(3):
+        d.iterate()
+        o.iterate()
+    d.create_data_from_object(np.flip(obj, 1).copy(), 5e10, random_seed=4)      # ref:496-512 does not touch estimate
+    o.create_data_from_object(np.flip(obj, 1).copy(), 5e10, noisy_measurement=d.noisy_measurement)
+    d.iterate()
+    o.iterate()
+    assert d.num_iterations == 4
+    assert max_rel(d.estimate, o.estimate) < 1e-10
+
+
+def test_operators_on_other_shapes_leave_the_state_alone(st, views, obj, tmp_path):
+    a = st.Deconvolver(views, str(tmp_path) + '/', verbose=False)
+    b = st.Deconvolver(views, str(tmp_path) + '/', verbose=False)
+    for d in (a, b):
+        d.create_data_from_object(obj, 5e10, random_seed=5)
+        d.iterate()
+    x = np.random.default_rng(0).random((2, 40, 48))
+    ref = orc.Deconvolver(views)
+    h = a.H(x)                                   # another shape: a plan of its own
+    assert all(max_rel(h[v], ref.H(x)[v]) < 1e-12 for v in range(2))
+    assert max_rel(a.H_t(h), ref.H_t(ref.H(x))) < 1e-12
+    a.iterate()
+    b.iterate()
+    assert np.array_equal(a.estimate, b.estimate)
+
+
+def test_multi_view_record_and_load_round_trip(st, views, obj, tmp_path):
+    prefix = str(tmp_path) + '/'
+    d = st.Deconvolver(views, prefix, verbose=False)
+    d.create_data_from_object(obj, 5e10, random_seed=6)
+    d.record_data()                              # noisy_measurement.tif: the two views stacked on axis 0 (ref:562-564)
+    for _ in range(3):
+        d.iterate()
+    e = st.Deconvolver(views, prefix, verbose=False)
+    e.load_data_from_tif(prefix + 'noisy_measurement.tif')
+    for _ in range(3):
+        e.iterate()
+    assert max_rel(e.estimate, d.estimate) < 1e-6      # the TIF stores float32
