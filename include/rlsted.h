@@ -200,6 +200,13 @@ int rl_psf_report(rl_ctx* ctx, int psf_type, double excitation_brightness, doubl
                   double steps_per_excitation_psf_width, double pulses_per_position,
                   double* arrays_out, double* report_out);
 
+/* psf_report for n_sets parameter sets in one call (the sweeps of line_sted_figure_1.py:33-48 and
+ * line_sted_figure_a1.py:29,64,102,172): one launch per pipeline stage over all sets, the Gaussian fits of
+ * all sets on the host in between.  params[n_sets][5] = { psf_type (0 / 1), excitation_brightness,
+ * depletion_brightness, steps_per_excitation_psf_width, pulses_per_position }; report_out[n_sets][8] as
+ * rl_psf_report, bit for bit; arrays_out: NULL, or n_sets pointers, each NULL or [5 | 7][n][n].        */
+int rl_psf_report_batch(rl_ctx* ctx, int n_sets, const double* params, double* report_out, double* const* arrays_out);
+
 /* rotate of line_sted_figure_2.py:264-272 for one [ny][nx] plane (general angles; the
  * caller keeps the script's exact 0 and 90 degree special cases): cubic B-spline
  * rotation about the centre as scipy.ndimage.rotate(order=3, reshape=False), then

@@ -4,6 +4,8 @@
 // phases run on the host (gauss_fit.cpp).
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "ctx.hpp"
@@ -255,6 +257,219 @@ int rl_psf_report(rl_ctx* ctx, int psf_type, double exc_b, double dep_b, double 
     report_out[5] = (double)n;
     report_out[6] = sc[0];
     report_out[7] = sc[8];
+    return RL_OK;
+}
+
+// psf_report for many parameter sets at once (line_sted_figure_1.py:33-48 sweeps 480 of them,
+// line_sted_figure_a1.py:29,64,102,172 a few hundred more): one launch per pipeline stage over all sets
+// instead of ~20 launches and two synchronisations per set.  Sets that share (psf_type, sampling) share
+// the blurred delta and its double blur, which depend on nothing else (:183-213).  Every set's numbers
+// are bit for bit those of rl_psf_report: same per-element arithmetic, same reduction order.
+//   params[n_sets][5] = { psf_type (0 point / 1 line), excitation_brightness, depletion_brightness,
+//                         steps_per_excitation_psf_width, pulses_per_position }
+//   report_out[n_sets][8] as rl_psf_report; arrays_out: NULL, or n_sets pointers (each NULL or
+//   [5 | 7][n][n] as rl_psf_generate).
+int rl_psf_report_batch(rl_ctx* ctx, int n_sets, const double* params, double* report_out, double* const* arrays_out) {
+    if (!ctx || !params || !report_out) return fail(RL_ERR_INVALID, "NULL argument");
+    if (n_sets < 1) return fail(RL_ERR_INVALID, "n_sets < 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    struct Group { int type, n, radius; double sigma; std::vector<double> w; long long g, gmax, w_off, ryx; };
+    std::map<std::pair<int, long long>, int> group_of;     // (type, bits of steps) -> group
+    std::vector<Group> groups;
+    std::vector<PsfSetDesc> sets(n_sets);
+    std::vector<double> sigma(n_sets), pulses(n_sets);
+    long long top = 0;     // workspace carving, in doubles
+    auto carve = [&](size_t count) { const long long o = top; top += (long long)((count + 1) & ~(size_t)1); return o; };
+    int max_n = 0;
+    for (int i = 0; i < n_sets; ++i) {
+        const double* q = params + 5 * (size_t)i;
+        const int type = (int)q[0];
+        if ((type != 0 && type != 1) || (double)type != q[0]) return fail(RL_ERR_INVALID, "psf_type must be 0 (point) or 1 (line)");
+        const double steps = q[3];
+        const double bs = steps / (2 * std::sqrt(2 * std::log(2.0)));                    // :91
+        const int n = 1 + 2 * (int)std::nearbyint(5 * bs);                               // :92
+        if (!(bs > 1e-15) || n < 3 || n > 4096) return fail(RL_ERR_INVALID, "steps_per_excitation_psf_width out of range");
+        long long bits;
+        memcpy(&bits, &steps, 8);
+        auto key = std::make_pair(type, bits);
+        auto it = group_of.find(key);
+        if (it == group_of.end()) {
+            Group g;
+            g.type = type; g.n = n; g.sigma = bs;
+            g.w = gaussian_weights(bs, 4.0, &g.radius);
+            g.g = carve(2 * (size_t)n * n);
+            g.gmax = carve(2);
+            g.w_off = carve(g.w.size());
+            g.ryx = carve(2 * (size_t)n);
+            it = group_of.emplace(key, (int)groups.size()).first;
+            groups.push_back(std::move(g));
+        }
+        const Group& g = groups[it->second];
+        PsfSetDesc& d = sets[i];
+        d.type = type; d.n = n; d.radius = g.radius; d.ratio = 0;
+        d.exc_b = q[1]; d.dep_b = q[2];
+        d.g = g.g; d.gmax = g.gmax; d.w = g.w_off; d.ryx = g.ryx;
+        d.arrays = carve(7 * (size_t)n * n);
+        d.b0 = carve(n);
+        d.scal = carve(32);
+        d.cumu = 0;
+        sigma[i] = bs;
+        pulses[i] = q[4];
+        max_n = std::max(max_n, n);
+    }
+    const long long fixed_top = top;
+    const long long scratch = carve(3 * (size_t)max_n * max_n);   // delta, tmp of the group blurs
+    double* base = nullptr;
+    // the rescan rings are sized after the fits; reserve for ratio <= 16 now (grown below if ever needed)
+    long long ring_reserve = 0;
+    for (const PsfSetDesc& d : sets)
+        if (d.type == 1) ring_reserve += 16LL * d.n * d.n;
+    RL_TRY(ctx->psf_workspace((size_t)(top + ring_reserve) + 64, &base));
+
+    // ---- per shape group: g = blur(delta), outer = blur(g), their maxima, the impulse responses ----
+    for (const Group& g : groups) {
+        const int n = g.n;
+        double *w = base + g.w_off, *G = base + g.g, *outer = G + (size_t)n * n, *delta = base + scratch, *tmp = delta + (size_t)max_n * max_n;
+        HIP_TRY(hipMemcpyAsync(w, g.w.data(), g.w.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(psf_delta(delta, n, n, g.type, s));
+        auto blur = [&](const double* in, double* out) -> int {
+            if (g.type == 0) {
+                HIP_TRY(psf_blur_axis(in, out, 1, n, n, 0, w, g.radius, s));
+                HIP_TRY(psf_blur_axis(out, tmp, 1, n, n, 1, w, g.radius, s));
+                HIP_TRY(psf_blur_axis(tmp, out, 1, n, n, 2, w, g.radius, s));
+            } else {
+                HIP_TRY(psf_blur_axis(in, out, 1, n, n, 2, w, g.radius, s));
+            }
+            return RL_OK;
+        };
+        RL_TRY(blur(delta, G));
+        RL_TRY(blur(G, outer));
+        HIP_TRY(psf_reduce(G, n * n, 1, 0, base + g.gmax, s));
+        HIP_TRY(psf_reduce(outer, n * n, 1, 0, base + g.gmax + 1, s));
+        if (g.type == 1) {
+            HIP_TRY(psf_delta(tmp, n, 1, 0, s));
+            HIP_TRY(psf_blur_axis(tmp, base + g.ryx, 1, n, 1, 1, w, g.radius, s));
+            HIP_TRY(psf_delta(tmp, 1, n, 1, s));
+            HIP_TRY(psf_blur_axis(tmp, base + g.ryx + n, 1, 1, n, 2, w, g.radius, s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));   // the groups' host weight vectors were copied asynchronously
+
+    // ---- all sets: saturation maths ----
+    PsfSetDesc* d_sets = nullptr;
+    ReduceJob* d_jobs = nullptr;
+    std::vector<ReduceJob> jobs;
+    HIP_TRY(hipMalloc((void**)&d_sets, sizeof(PsfSetDesc) * n_sets));
+    HIP_TRY(hipMalloc((void**)&d_jobs, sizeof(ReduceJob) * 16 * n_sets));
+    struct Free { void *a, *b; ~Free() { (void)hipFree(a); (void)hipFree(b); } } free_guard{d_sets, d_jobs};
+    auto run_jobs = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(ReduceJob) * jobs.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(psf_reduce_jobs(base, base, d_jobs, (int)jobs.size(), s));
+        HIP_TRY(hipStreamSynchronize(s));
+        jobs.clear();
+        return RL_OK;
+    };
+    HIP_TRY(hipMemcpyAsync(d_sets, sets.data(), sizeof(PsfSetDesc) * n_sets, hipMemcpyHostToDevice, s));
+    HIP_TRY(psf_batch_stage1(base, d_sets, n_sets, max_n, s));
+    for (const PsfSetDesc& d : sets) jobs.push_back({d.arrays + (long long)d.n * d.n, d.scal + 2, d.n * d.n, 1, 0, 0});   // max dep_raw
+    RL_TRY(run_jobs());
+    HIP_TRY(psf_batch_stage2(base, d_sets, n_sets, max_n, s));
+
+    // ---- line sets: central sted rows -> host fits -> integer rescan ratios (:252-256) -> rescan simulation ----
+    std::vector<std::vector<double>> sted_rows(n_sets);
+    for (int i = 0; i < n_sets; ++i) {
+        const PsfSetDesc& d = sets[i];
+        sted_rows[i].resize(d.n);
+        HIP_TRY(hipMemcpyAsync(sted_rows[i].data(), base + d.arrays + 4 * (size_t)d.n * d.n + (size_t)(d.n / 2) * d.n,
+                               d.n * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<double> ratio_ideal(n_sets, 0.0), sted_fit(n_sets);
+    long long ring_top = top;
+    int max_ratio = 0;
+    bool any_line = false;
+    for (int i = 0; i < n_sets; ++i) {
+        PsfSetDesc& d = sets[i];
+        double fit[3];
+        gauss_fit_lmdif(sted_rows[i].data(), d.n, fit);          // the same fit serves :108 and :252
+        sted_fit[i] = fit[2];
+        if (d.type != 1) continue;
+        any_line = true;
+        ratio_ideal[i] = (sigma[i] / fit[2]) * (sigma[i] / fit[2]) + 1.0;
+        d.ratio = (int)std::nearbyint(ratio_ideal[i]);
+        if (d.ratio < 1 || d.ratio > 4096) return fail(RL_ERR_INVALID, "line rescan ratio out of range");
+        d.cumu = ring_top;
+        ring_top += (long long)d.ratio * d.n * d.n;
+        max_ratio = std::max(max_ratio, d.ratio);
+    }
+    if (any_line) {
+        if (ring_top > top + ring_reserve) {     // larger rings than reserved: grow (offsets stay valid: same carving)
+            std::vector<double> keep((size_t)fixed_top);
+            HIP_TRY(hipMemcpy(keep.data(), base, keep.size() * 8, hipMemcpyDeviceToHost));
+            RL_TRY(ctx->psf_workspace((size_t)ring_top + 64, &base));
+            HIP_TRY(hipMemcpy(base, keep.data(), keep.size() * 8, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMemcpyAsync(d_sets, sets.data(), sizeof(PsfSetDesc) * n_sets, hipMemcpyHostToDevice, s));
+        HIP_TRY(psf_batch_rescan(base, d_sets, n_sets, max_n, max_ratio, s));
+    }
+
+    // ---- sums, maxima (:105-106,120,134-144) ----
+    for (const PsfSetDesc& d : sets) {
+        const long long nn = (long long)d.n * d.n, row = (long long)(d.n / 2) * d.n;
+        const long long arr3[3] = {d.arrays, d.arrays + nn, d.arrays + 4 * nn};
+        for (int k = 0; k < 3; ++k) {
+            jobs.push_back({arr3[k], d.scal + 16 + k, (int)nn, 1, 1, 0});
+            jobs.push_back({arr3[k] + row, d.scal + 16 + 3 + k, d.n, 1, 1, 0});
+        }
+        jobs.push_back({d.arrays, d.scal + 4, (int)nn, 1, 0, 0});
+        jobs.push_back({d.arrays + row, d.scal + 5, d.n, 1, 0, 0});
+        jobs.push_back({d.arrays + 4 * nn, d.scal + 6, (int)nn, 1, 0, 0});
+        jobs.push_back({d.arrays + 4 * nn + row, d.scal + 7, d.n, 1, 0, 0});
+        if (d.type == 1) {
+            jobs.push_back({d.arrays + 6 * nn, d.scal + 8, (int)nn, 1, 0, 0});
+            jobs.push_back({d.arrays + 6 * nn + row, d.scal + 9, d.n, 1, 0, 0});
+        }
+    }
+    RL_TRY(run_jobs());
+    std::vector<double> scal(32 * (size_t)n_sets), rescan_row;
+    for (int i = 0; i < n_sets; ++i)
+        HIP_TRY(hipMemcpyAsync(scal.data() + 32 * (size_t)i, base + sets[i].scal, 32 * 8, hipMemcpyDeviceToHost, s));
+    std::vector<std::vector<double>> rescan_rows(n_sets);
+    for (int i = 0; i < n_sets; ++i) {
+        const PsfSetDesc& d = sets[i];
+        if (d.type == 1) {
+            rescan_rows[i].resize(d.n);
+            HIP_TRY(hipMemcpyAsync(rescan_rows[i].data(), base + d.arrays + 6 * (size_t)d.n * d.n + (size_t)(d.n / 2) * d.n,
+                                   d.n * 8, hipMemcpyDeviceToHost, s));
+        }
+        if (arrays_out && arrays_out[i])
+            HIP_TRY(hipMemcpyAsync(arrays_out[i], base + d.arrays, (size_t)(d.type == 1 ? 7 : 5) * d.n * d.n * 8,
+                                   hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < n_sets; ++i) {
+        const PsfSetDesc& d = sets[i];
+        const double* hm = scal.data() + 32 * (size_t)i;
+        const double* hs = hm + 16;
+        double* r = report_out + 8 * (size_t)i;
+        r[0] = sigma[i] / sted_fit[i];
+        r[1] = std::nan("");
+        if (d.type == 1) {
+            double fit[3];
+            gauss_fit_lmdif(rescan_rows[i].data(), d.n, fit);      // :121
+            r[1] = sigma[i] / fit[2];
+        }
+        const int o = d.type == 0 ? 0 : 3;
+        r[2] = pulses[i] * hs[o];
+        r[3] = pulses[i] * hs[o + 1];
+        r[4] = pulses[i] * hs[o + 2];
+        r[5] = (double)d.n;
+        r[6] = (double)d.ratio;
+        bool peaks = hm[4] == hm[5] && hm[6] == hm[7];
+        if (d.type == 1) peaks = peaks && hm[8] == hm[9];
+        r[7] = peaks ? 1.0 : 0.0;
+    }
     return RL_OK;
 }
 

@@ -224,6 +224,110 @@ __global__ void k_spline_rotate(const double* __restrict__ coef, double* __restr
     out[e] = r < 0.0 ? 0.0 : (r > hi ? hi : r);
 }
 
+
+// ---- batched PSF pipeline: the same per-element arithmetic and the same reduction order as the single-set
+// kernels above, blockIdx.y (or the job index) selecting the parameter set -- results are bit for bit those
+// of rl_psf_report called set by set.
+__global__ void __launch_bounds__(1024) k_reduce_jobs(const double* __restrict__ base, double* __restrict__ out_base,
+                                                      const ReduceJob* __restrict__ jobs) {
+    __shared__ double part[16];
+    const ReduceJob jb = jobs[blockIdx.x];
+    const double* in = base + jb.off;
+    const int op = jb.op;
+    double v = op == 0 ? -1.0e308 : 0.0;
+    for (int i = threadIdx.x; i < jb.count; i += blockDim.x) {
+        const double x = in[(size_t)i * jb.stride];
+        v = op == 0 ? (x > v ? x : v) : v + x;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(v, off, 64);
+        v = op == 0 ? (o > v ? o : v) : v + o;
+    }
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = (blockDim.x + 63) / 64;
+        v = lane < nw ? part[lane] : (op == 0 ? -1.0e308 : 0.0);
+        for (int off = 8; off > 0; off >>= 1) {
+            const double o = __shfl_down(v, off, 64);
+            v = op == 0 ? (o > v ? o : v) : v + o;
+        }
+        if (lane == 0) out_base[jb.out] = v;
+    }
+}
+
+__global__ void k_batch_stage1(double* __restrict__ base, const PsfSetDesc* __restrict__ sets) {
+    const PsfSetDesc d = sets[blockIdx.y];
+    const int n = d.n * d.n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double* g = base + d.g;
+    const double* outer = g + n;
+    const double mg = base[d.gmax], mo = base[d.gmax + 1];
+    double* exc = base + d.arrays;
+    exc[e] = g[e] * (d.exc_b / mg);
+    exc[n + e] = (outer[e] / mo) - (g[e] / mg);      // dep_raw
+}
+__global__ void k_batch_stage2(double* __restrict__ base, const PsfSetDesc* __restrict__ sets) {
+    const PsfSetDesc d = sets[blockIdx.y];
+    const int n = d.n * d.n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double* exc = base + d.arrays;
+    double *dep = exc + n, *excf = dep + n, *depf = excf + n, *sted = depf + n;
+    const double dv = dep[e] * (d.dep_b / base[d.scal + 2]);
+    dep[e] = dv;
+    const double ef = 1.0 - exp2(-exc[e] / 1.0);
+    const double df = exp2(-dv / 1.0);
+    excf[e] = ef;
+    depf[e] = df;
+    sted[e] = ef * df;
+}
+__global__ void k_batch_rescan_b0(double* __restrict__ base, const PsfSetDesc* __restrict__ sets) {
+    const PsfSetDesc d = sets[blockIdx.y];
+    const int sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.type != 1 || sp >= d.n) return;
+    const int n = d.n, radius = d.radius;
+    const double* sted_row = base + d.arrays + 4 * (size_t)n * n + (size_t)(n / 2) * n;
+    const double* w = base + d.w;
+    const double a = sted_row[wrap(2 * (n / 2) - sp, n)];
+    double acc = a * w[radius];
+    for (int j = -radius; j < 0; ++j) acc += (a + a) * w[radius + j];
+    base[d.b0 + sp] = acc;
+}
+__global__ void k_batch_descan(double* __restrict__ base, const PsfSetDesc* __restrict__ sets) {
+    const PsfSetDesc d = sets[blockIdx.y];
+    const int n = d.n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.type != 1 || e >= n * n) return;
+    const double *b0 = base + d.b0, *ry = base + d.ryx, *rx = ry + n;
+    const int sp = e % n, y = e / n, c = n / 2;
+    double acc = 0.0;
+    for (int x = 0; x < n; ++x) acc += blurred(b0, ry, rx, sp, y, wrap(x - (c - sp), n));
+    base[d.arrays + 5 * (size_t)n * n + e] = acc;
+}
+__global__ void k_batch_rescan_cumu(double* __restrict__ base, const PsfSetDesc* __restrict__ sets) {
+    const PsfSetDesc d = sets[blockIdx.y];
+    const int n = d.n, rn = d.ratio * n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.type != 1 || e >= n * rn) return;
+    const double *b0 = base + d.b0, *ry = base + d.ryx, *rx = ry + n;
+    const int X = e % rn, y = e / rn, c = n / 2;
+    double acc = 0.0;
+    for (int sp = 0; sp < n; ++sp) {
+        const int xp = wrap(X - (sp * d.ratio - c), rn);
+        if (xp < n) acc += blurred(b0, ry, rx, sp, y, wrap(xp - (c - sp), n));
+    }
+    base[d.cumu + e] = acc;
+}
+__global__ void k_batch_rescan_bin(double* __restrict__ base, const PsfSetDesc* __restrict__ sets) {
+    const PsfSetDesc d = sets[blockIdx.y];
+    const int n = d.n, rn = d.ratio * n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.type != 1 || e >= n * n) return;
+    const double* cumu = base + d.cumu;
+    const int j = e % n, y = e / n;
+    double acc = 0.0;
+    for (int q = 0; q < d.ratio; ++q) acc += cumu[(size_t)y * rn + wrap(j * d.ratio + q - d.ratio / 2, rn)];
+    base[d.arrays + 6 * (size_t)n * n + e] = acc;
+}
+
 static inline unsigned nblk(int n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t psf_blur_axis(const double* in, double* out, int nz, int ny, int nx, int axis, const double* w, int radius,
@@ -269,6 +373,27 @@ hipError_t psf_spline_rotate(const double* in, double* work, double* out, double
     k_spline_prefilter<<<nblk(ny), 256, 0, s>>>(work, ny, nx, 1);
     const double th = degrees * 0.017453292519943295769236907684886;
     k_spline_rotate<<<nblk(ny * nx), 256, 0, s>>>(work, out, ny, nx, cos(th), sin(th), vmax);
+    return hipGetLastError();
+}
+
+
+hipError_t psf_reduce_jobs(const double* base, double* out_base, const ReduceJob* jobs, int n_jobs, hipStream_t s) {
+    if (n_jobs > 0) k_reduce_jobs<<<n_jobs, 1024, 0, s>>>(base, out_base, jobs);
+    return hipGetLastError();
+}
+hipError_t psf_batch_stage1(double* base, const PsfSetDesc* sets, int n_sets, int max_n, hipStream_t s) {
+    k_batch_stage1<<<dim3(nblk(max_n * max_n), n_sets), 256, 0, s>>>(base, sets);
+    return hipGetLastError();
+}
+hipError_t psf_batch_stage2(double* base, const PsfSetDesc* sets, int n_sets, int max_n, hipStream_t s) {
+    k_batch_stage2<<<dim3(nblk(max_n * max_n), n_sets), 256, 0, s>>>(base, sets);
+    return hipGetLastError();
+}
+hipError_t psf_batch_rescan(double* base, const PsfSetDesc* sets, int n_sets, int max_n, int max_ratio, hipStream_t s) {
+    k_batch_rescan_b0<<<dim3(nblk(max_n), n_sets), 256, 0, s>>>(base, sets);
+    k_batch_descan<<<dim3(nblk(max_n * max_n), n_sets), 256, 0, s>>>(base, sets);
+    k_batch_rescan_cumu<<<dim3(nblk(max_n * max_n * max_ratio), n_sets), 256, 0, s>>>(base, sets);
+    k_batch_rescan_bin<<<dim3(nblk(max_n * max_n), n_sets), 256, 0, s>>>(base, sets);
     return hipGetLastError();
 }
 

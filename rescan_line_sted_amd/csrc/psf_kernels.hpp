@@ -17,3 +17,27 @@ hipError_t psf_rescan(const double* sted_row, const double* w, int radius, const
 hipError_t psf_spline_rotate(const double* in, double* work, double* out, double* vmax, int ny, int nx,
                              double degrees, hipStream_t s);
 }  // namespace rl
+
+// ---- batched PSF pipeline (rl_psf_report_batch): one launch per stage over all parameter sets ----
+namespace rl {
+struct PsfSetDesc {          // one parameter set; offsets are in doubles from the batch workspace base
+    int type, n, radius, ratio;
+    double exc_b, dep_b;
+    long long g;             // the set's shape group: g [n*n], outer [n*n] behind it
+    long long gmax;          // group maxima: max g, max outer
+    long long w;             // Gaussian weights of the group (2 radius + 1)
+    long long ryx;           // group impulse responses ry [n], rx [n]
+    long long arrays;        // exc, dep, exc_frac, dep_frac, sted, descan, rescan  (7 x n*n)
+    long long b0;            // [n]
+    long long cumu;          // [n][ratio*n]
+    long long scal;          // 16 maxima + 16 sums
+};
+struct ReduceJob {           // out[] <- max (op 0) / sum (op 1) of base[off + i*stride], i < count
+    long long off, out;
+    int count, stride, op, pad;
+};
+hipError_t psf_reduce_jobs(const double* base, double* out_base, const ReduceJob* jobs, int n_jobs, hipStream_t s);
+hipError_t psf_batch_stage1(double* base, const PsfSetDesc* sets, int n_sets, int max_n, hipStream_t s);
+hipError_t psf_batch_stage2(double* base, const PsfSetDesc* sets, int n_sets, int max_n, hipStream_t s);
+hipError_t psf_batch_rescan(double* base, const PsfSetDesc* sets, int n_sets, int max_n, int max_ratio, hipStream_t s);
+}  // namespace rl

@@ -153,6 +153,51 @@ def psf_report(psf_type, excitation_brightness, depletion_brightness,
     return out
 
 
+def psf_report_batch(parameter_sets, with_psfs=False):
+    """psf_report (ref:75-166) for a list of parameter sets in ONE device pass (rl_psf_report_batch): the
+    sweeps of line_sted_figure_1.py:33-48 (480 sets) and line_sted_figure_a1.py.  parameter_sets: iterable
+    of (psf_type, excitation_brightness, depletion_brightness, steps_per_excitation_psf_width,
+    pulses_per_position) tuples or dicts with those keys.  Returns one psf_report dict per set, each bit
+    for bit what psf_report returns ('psfs' only when with_psfs)."""
+    import ctypes
+    keys = ('psf_type', 'excitation_brightness', 'depletion_brightness', 'steps_per_excitation_psf_width',
+            'pulses_per_position')
+    sets = [tuple(p[k] for k in keys) if isinstance(p, dict) else tuple(p) for p in parameter_sets]
+    for p in sets:
+        if p[0] not in _TYPES:
+            raise UnboundLocalError("psf_type must be 'point' or 'line'")
+    n_sets = len(sets)
+    if n_sets == 0:
+        return []
+    params = np.array([[_TYPES[p[0]]] + [float(v) for v in p[1:]] for p in sets], dtype=np.float64)
+    rep = np.zeros((n_sets, 8))
+    arrays, ptrs = [], None
+    if with_psfs:
+        dp = ctypes.POINTER(ctypes.c_double)
+        ptrs = (dp * n_sets)()
+        for i, p in enumerate(sets):
+            n = 1 + 2 * int(np.round(5 * (p[3] / _FWHM)))
+            arrays.append(np.empty((5 if p[0] == 'point' else 7, n, n), dtype=np.float64))
+            ptrs[i] = arrays[i].ctypes.data_as(dp)
+    check(lib.rl_psf_report_batch(_ctx().handle, n_sets, ptr(params), ptr(rep), ptrs))
+    out = []
+    for i, p in enumerate(sets):
+        assert rep[i, 7] == 1.0          # ref:105-106,120: each PSF peaks on its central row
+        r = {}
+        if p[0] == 'line':
+            r['resolution_improvement_rescanned'] = rep[i, 1]
+        r['resolution_improvement_descanned'] = rep[i, 0]
+        r['excitation_dose'] = rep[i, 2]
+        r['depletion_dose'] = rep[i, 3]
+        r['expected_emission'] = rep[i, 4]
+        r['pulses_per_position'] = p[4]
+        if with_psfs:
+            n = int(rep[i, 5])
+            r['psfs'] = _as_dict(p[0], arrays[i], n, n)
+        out.append(r)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # tune_psf (ref:365-476).  The reference minimises with scipy.optimize.
 # minimize_scalar's default method: a golden-section bracket search started at

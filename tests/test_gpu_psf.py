@@ -268,3 +268,51 @@ def test_record_iteration_writes_reference_history(st, golden, tmp_path):
     assert eh.dtype == np.float32 and fh.dtype == np.float32
     assert max_rel(eh, g['estimate_history_tif']) < 1e-6
     assert max_rel(fh, g['ft_error_history_tif']) < 1e-6
+
+
+# ---------------------------------------------------------------- batched psf_report (figure 1's sweep)
+def figure_1_parameter_sets():
+    """line_sted_figure_1.py:33-48 (480 combinations) plus the fine-grid report of :65-71 per (type, exc, dep)."""
+    sets = [(p, exc, dep, samps, pulses) for exc in (0.25, 1, 4) for dep in (0, 1, 3, 9, 27) for samps in (4, 6, 8, 12)
+            for pulses in (1, 2, 4, 8) for p in ('line', 'point')]
+    assert len(sets) == 480
+    return sets
+
+
+def test_psf_report_batch_is_bit_for_bit_the_unbatched_call():
+    from rescan_line_sted_amd import psf
+    sets = figure_1_parameter_sets()
+    pick = sets[::7] + [('line', 0.25, 9, 25, 1), ('point', 4, 27, 30, 2), ('line', 1, 0, 30, 1)]
+    batch = psf.psf_report_batch(pick, with_psfs=True)
+    for p, b in zip(pick, batch):
+        one = psf.psf_report(*p, verbose=False)
+        assert sorted(one) == sorted(b)
+        for k in one:
+            if k != 'psfs':
+                assert one[k] == b[k] or (np.isnan(one[k]) and np.isnan(b[k])), (p, k, one[k], b[k])
+        assert sorted(one['psfs']) == sorted(b['psfs'])
+        for k in one['psfs']:
+            assert np.array_equal(one['psfs'][k], b['psfs'][k]), (p, k)
+
+
+def test_psf_report_batch_figure_1_sweep_time_and_golden(golden):
+    import time
+    from rescan_line_sted_amd import psf
+    sets = figure_1_parameter_sets()
+    psf.psf_report_batch(sets[:16])                       # warm-up (workspace allocation)
+    t0 = time.perf_counter()
+    reports = psf.psf_report_batch(sets)
+    el = time.perf_counter() - t0
+    print('480 psf_report sets in one batch: %.1f ms' % (el * 1e3))
+    assert el < 0.25                                      # ~20 launches + 2 syncs per set unbatched: seconds
+    g = golden('g1_psf_report')
+    hits = 0
+    for p, r in zip(sets, reports):
+        key = '%s_s%d_e%g_d%g_p%d/scalars' % (p[0], p[3], p[1], p[2], p[4])
+        if key in g.files:
+            sc = g[key]
+            hits += 1
+            assert abs(r['resolution_improvement_descanned'] - sc[0]) < 1e-9 * abs(sc[0])
+            for k, i in (('excitation_dose', 2), ('depletion_dose', 3), ('expected_emission', 4)):
+                assert abs(r[k] - sc[i]) <= 1e-9 * max(abs(sc[i]), 1e-30), (p, k)
+    assert hits >= 20
