@@ -178,6 +178,37 @@ hipError_t aux_psf_spectrum(int dtype, const double* psf_dev, const void* wx_dev
     return hipGetLastError();
 }
 
+// Real parts of a complex array + max |im| and max |z| (stats[0], stats[1]; zeroed by the caller): a
+// point-symmetric PSF has a real spectrum, which the column kernels can then use as a real multiplier.
+// Non-negative doubles order like their bit patterns, so the maxima are integer atomics.
+template <typename T>
+__global__ void k_split_real(const cx<T>* __restrict__ z, size_t n, T* __restrict__ re, double* __restrict__ stats) {
+    double im = 0.0, ab = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {   // grid stride
+        const cx<T> v = z[i];
+        re[i] = v.re;
+        im = fmax(im, fabs((double)v.im));
+        ab = fmax(ab, fmax(fabs((double)v.re), fabs((double)v.im)));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        im = fmax(im, __shfl_down(im, off, 64));
+        ab = fmax(ab, __shfl_down(ab, off, 64));
+    }
+    if (threadIdx.x % 64 == 0) {
+        atomicMax((unsigned long long*)stats, (unsigned long long)__double_as_longlong(im));
+        atomicMax((unsigned long long*)stats + 1, (unsigned long long)__double_as_longlong(ab));
+    }
+}
+
+hipError_t aux_split_real(int dtype, const void* z, size_t n, void* re, double* stats, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    const unsigned g = blocks_for(n, 256);
+    if (dtype == DT_F32) k_split_real<float><<<g, 256, 0, s>>>((const cx<float>*)z, n, (float*)re, stats);
+    else k_split_real<double><<<g, 256, 0, s>>>((const cx<double>*)z, n, (double*)re, stats);
+    return hipGetLastError();
+}
+
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s,
                        const unsigned long long* frame_seeds, const unsigned* frame_ids, unsigned V) {

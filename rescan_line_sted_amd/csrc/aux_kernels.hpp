@@ -25,4 +25,6 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
                              double* sums, hipStream_t s);
 hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s);
+// re[i] = z[i].re for n complex values of `dtype`; stats (device, 2 doubles) <- max |im|, max(|re|, |im|)
+hipError_t aux_split_real(int dtype, const void* z, size_t n, void* re, double* stats, hipStream_t s);
 }  // namespace rl

@@ -83,6 +83,10 @@ struct ColParams {
     int mode;               // ColMode (wave-private column kernel only; others: per image)
     int images;             // streaming kernel: output images covered by the launch (grid.y of the tiled kernel)
     int order;              // tiled kernel's work order: images per block of the tile order (1 = image-major)
+    // A point-symmetric PSF has a real spectrum: its real parts alone, same indexing as the transposed
+    // psf_hat ([view][kx][L]); used by the REALP instantiations of the wave-private column kernel
+    // (half the multiplier bytes, a real x complex product).  nullptr: the complex multiplier.
+    const T* psf_hat_re = nullptr;
 };
 
 template <class Cfg, int C, typename T, class Sync>
@@ -173,7 +177,7 @@ enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2 };
 
 // MODE is a compile-time parameter: each mode is its own kernel, so the single-view path
 // does not inherit the register footprint of the multi-view loops.
-template <class Cfg, int C, int MODE, typename T, class Sync>
+template <class Cfg, int C, int MODE, typename T, bool REALP = false, class Sync>
 RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
     constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value;
@@ -216,17 +220,30 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     };
     // v, tl *= psf_hat[view] column (register layout of the last forward pass)
     auto multiply = [&](cx<T>* v, cx<T>& tl, int view) {
-        const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
+        if constexpr (REALP) {   // real spectrum of a point-symmetric PSF
+            const T* __restrict__ ph = p.psf_hat_re + ((size_t)view * p.kx + col) * L;
 #pragma unroll
-        for (int nb = 0; nb < FL::NBM; ++nb) {
-            const int j = lane + nb * 64;
-            if (j < FL::NBF) {
+            for (int nb = 0; nb < FL::NBM; ++nb) {
+                const int j = lane + nb * 64;
+                if (j < FL::NBF) {
 #pragma unroll
-                for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[j + r * FL::NBF]);
+                    for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = scale(v[nb * FL::R + r], ph[j + r * FL::NBF]);
+                }
             }
+            if constexpr (FL::TAIL) tl = scale(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
+        } else {
+            const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
+#pragma unroll
+            for (int nb = 0; nb < FL::NBM; ++nb) {
+                const int j = lane + nb * 64;
+                if (j < FL::NBF) {
+#pragma unroll
+                    for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[j + r * FL::NBF]);
+                }
+            }
+            if constexpr (FL::TAIL)   // the tail value is output bitrev3(p) of butterfly 64 + jj
+                tl = cmul(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
         }
-        if constexpr (FL::TAIL)   // the tail value is output bitrev3(p) of butterfly 64 + jj
-            tl = cmul(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
     };
     // inverse transform of (v, tl), result in natural order into this wave's LDS column
     auto inverse_to_lds = [&](cx<T>* v, cx<T>& tl, const cx<T>* tw) {
@@ -344,6 +361,10 @@ struct RowParams {
     const cx<T>* tw;        // [Lx]
     int ny, nx, pitch, V;
     int frames;             // streaming kernels: images covered by the launch (grid.y of the tiled kernels)
+    // > 0: image i reads input spectrum i % in_mod (single-spectrum modes).  The first RL iteration starts
+    // from estimate = 1 (ref:522), whose H(est) is the same for every frame: its V column-transformed
+    // spectra are computed once per plan and every frame's ROW_RATIO reads them.
+    int in_mod = 0;
 };
 
 // ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.
@@ -399,7 +420,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             for (int s = 0; s < NB * R; ++s) acc[s] = mk<T>((T)0, (T)0);
         }
         for (int vw = 0; vw < nview; ++vw) {
-            const size_t im = MULTI ? (size_t)by * p.V + vw : (size_t)by;
+            const size_t im = MULTI ? (size_t)by * p.V + vw : (p.in_mod > 0 ? (size_t)(by % p.in_mod) : (size_t)by);
             const cx<T>* __restrict__ sp = p.spec_in + im * simg;
             fft_sync<Cfg>(sync);   // LDS free
             // pack the two half spectra into one Hermitian-free complex row
@@ -739,7 +760,8 @@ struct RowSpectra {
     cx<T> A[NPK], B[NPK];
     template <class Sync>
     RL_HD void request(const RowParams<T>& p, int by, int r0, unsigned t, Sync& sync) {
-        const cx<T>* __restrict__ sa = p.spec_in + (size_t)by * spec_image_elems(p.ny, p.pitch) + spec_pair_off(r0 >> 1, p.pitch);
+        const cx<T>* __restrict__ sa = p.spec_in + (size_t)(p.in_mod > 0 ? by % p.in_mod : by) * spec_image_elems(p.ny, p.pitch) +
+                                       spec_pair_off(r0 >> 1, p.pitch);
         const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? spec_odd_row(p.pitch) : 0u);
         const unsigned lane = spec_pair_col(t);
 #pragma unroll

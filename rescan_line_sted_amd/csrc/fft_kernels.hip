@@ -62,7 +62,7 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 // NOTE: the transform length is a template parameter of the kernels so that the
 // kernels of different lengths (built in separate translation units) have
 // distinct symbol names.
-template <int L, int C, int MODE, typename T>
+template <int L, int C, int MODE, typename T, bool REALP = false>
 __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && MODE == COL_PER_IMAGE && WavePrivate<typename ColCfgFor<L>::type>::value) ? RL_COL_MIN_WAVES : 1)
     k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && M
         }
     }
     if constexpr (WavePrivate<KCfg>::value)
-        colconv_wave_body<KCfg, C, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
+        colconv_wave_body<KCfg, C, MODE, T, REALP>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
         colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
@@ -296,14 +296,27 @@ static constexpr size_t col_lds_bytes() {
 template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
-    if (WavePrivate<CCfg>::value && p.mode == COL_H_MULTI)
-        rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T>, dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s, p);
-    else if (WavePrivate<CCfg>::value && p.mode == COL_HT_SUM)
-        rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T>, dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s, p);
-    else if (p.mode == COL_PER_IMAGE)
-        rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T>, dim3(gx, gy), dim3(CCfg::T * C), col_lds_bytes<C, T>(), s, p);
-    else
-        return hipErrorInvalidValue;
+    const dim3 grid(gx, gy), block(CCfg::T * C);
+    constexpr size_t lds = col_lds_bytes<C, T>();
+    if constexpr (WavePrivate<CCfg>::value) {
+        if (p.psf_hat_re) {   // real PSF spectrum
+            if (p.mode == COL_H_MULTI) rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T, true>, grid, block, lds, s, p);
+            else if (p.mode == COL_HT_SUM) rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T, true>, grid, block, lds, s, p);
+            else if (p.mode == COL_PER_IMAGE) rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T, true>, grid, block, lds, s, p);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        if (p.mode == COL_H_MULTI) {
+            rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T>, grid, block, lds, s, p);
+            return hipGetLastError();
+        }
+        if (p.mode == COL_HT_SUM) {
+            rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T>, grid, block, lds, s, p);
+            return hipGetLastError();
+        }
+    }
+    if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
+    rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T>, grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -364,6 +377,10 @@ static hipError_t prepare() {
     hipError_t e;
     if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
     if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double>, col_lds_bytes<kC64, double>())) != hipSuccess) return e;
+    if constexpr (WavePrivate<CCfg>::value) {
+        if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, true>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double, true>, col_lds_bytes<kC64, double>())) != hipSuccess) return e;
+    }
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
     return hipSuccess;

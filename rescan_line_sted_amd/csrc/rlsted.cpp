@@ -70,8 +70,13 @@ struct rl_deconv {
     void *twy = nullptr, *twx = nullptr;
     // device buffers (element type = dtype)
     void* psf_hat = nullptr;   // [V][ly][pitch] complex
+    void* psf_hat_re = nullptr;   // real parts, when the PSF spectrum is real (point-symmetric PSFs) and the column
+                                  // transform is wave private: the column kernels then multiply by a real array
+    double psf_hat_imag_ratio = 0;   // max |im| / max |z| of the PSF spectrum
     void* spec_a = nullptr;    // [B] spectrum images (layout: conv_kernels.hpp spec_off)
     void* spec_b = nullptr;    // [B*V] spectrum images
+    void* spec_ones = nullptr; // [V] column-transformed spectra of H(estimate = 1): the same for every frame (ref:522)
+    bool ones_shortcut = true; // first iteration reads spec_ones instead of transforming a frame of ones (RLSTED_ONES_SHORTCUT=0: off)
     void* obj = nullptr;       // [B][ny][nx]
     void* noiseless = nullptr; // [B*V][ny][nx]
     void* meas = nullptr;      // [B*V][ny][nx]
@@ -239,6 +244,7 @@ struct rl_deconv {
         p.in = (const cx<T>*)in;
         p.out = (cx<T>*)out;
         p.psf_hat = (const cx<T>*)psf_hat;
+        p.psf_hat_re = (const T*)psf_hat_re;
         p.tw = (const cx<T>*)twy;
         p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V;
         unsigned gy = (unsigned)(frames * V);
@@ -288,8 +294,9 @@ struct rl_deconv {
     int col(const void* in, void* out, int frames, bool h_mode) { return col(in, out, frames, h_mode ? COL_H : COL_HT_VIEW); }
     template <typename T>
     int row_t(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-              const void* scale, int views) {
+              const void* scale, int views, int in_mod = 0) {
         RowParams<T> p;
+        p.in_mod = in_mod;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
         p.src = (const T*)src;
@@ -318,19 +325,22 @@ struct rl_deconv {
         return RL_OK;
     }
     int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-            const void* scale = nullptr, int views = -1) {
+            const void* scale = nullptr, int views = -1, int in_mod = 0) {
         if (views < 0) views = V;
         const size_t sp = n_spec() * 2 * esize(dtype), im = n_img() * esize(dtype);
         const bool multi = mode == ROW_UPDATE || mode == ROW_ADJ;   // `views` input spectra per image
-        for (unsigned g0 = 0; g0 < gy; g0 += (unsigned)kMaxGridY) {
-            const unsigned ng = std::min((unsigned)kMaxGridY, gy - g0);
-            const void* si = spec_in ? (const char*)spec_in + (size_t)g0 * (multi ? (size_t)views : 1) * sp : nullptr;
+        const unsigned piece = in_mod > 0 ? (unsigned)(kMaxGridY / in_mod * in_mod) : (unsigned)kMaxGridY;
+        for (unsigned g0 = 0; g0 < gy; g0 += piece) {
+            const unsigned ng = std::min(piece, gy - g0);
+            // (kMaxGridY is a multiple of every in_mod in use only by accident: a shared input is not moved on,
+            // and the image index restarts at 0 in each piece -- so pieces must start on a multiple of in_mod)
+            const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)g0 * (multi ? (size_t)views : 1) * sp) : nullptr;
             void* so = spec_out ? (char*)spec_out + (size_t)g0 * sp : nullptr;
             const void* sr = src ? (const char*)src + (size_t)g0 * im : nullptr;
             void* ds = dst ? (char*)dst + (size_t)g0 * im : nullptr;
             const void* sc = scale ? (const char*)scale + (size_t)g0 * esize(dtype) : nullptr;
-            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views)
-                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views));
+            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod)
+                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod));
         }
         return RL_OK;
     }
@@ -412,10 +422,13 @@ struct rl_deconv {
         if (c > 8) c = (c + 7) / 8 * 8;
         return c;
     }
-    int start_estimate_chunk(int f0, int nf) {
+    // estimate = 1 (ref:522).  with_spectrum: also spec_a = rowFFT(estimate); the first iteration does not need
+    // it when it takes H(1) from spec_ones (iterate_chunk(first = true)).
+    int start_estimate_chunk(int f0, int nf, bool with_spectrum = true) {
         HIP_TRY(aux_fill(dtype, off(est, (size_t)f0 * n_img()), (size_t)nf * n_img(), 1.0, cur()));
-        RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, off(spec_a, (size_t)f0 * n_spec() * 2), off(est, (size_t)f0 * n_img()),
-                   nullptr, nullptr));
+        if (with_spectrum)
+            RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, off(spec_a, (size_t)f0 * n_spec() * 2), off(est, (size_t)f0 * n_img()),
+                       nullptr, nullptr));
         return RL_OK;
     }
     int ensure_lanes() {
@@ -427,9 +440,17 @@ struct rl_deconv {
         }
         return RL_OK;
     }
-    int iterate_chunk(int f0, int nf) {
+    // first: the iteration starts from estimate = 1 (just filled): H(estimate) is spec_ones for every frame, so the
+    // column pass of H is skipped and ROW_RATIO reads the shared spectra (bit for bit what the pass would write)
+    int iterate_chunk(int f0, int nf, bool first = false) {
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
+        if (first && V == 1 && inplace) {
+            RL_TRY(row(ROW_RATIO, (unsigned)nf, spec_ones, sa, off(meas, (size_t)f0 * n_img()), nullptr, nullptr, nullptr, -1, 1));
+            RL_TRY(col(sa, sa, nf, false));
+            RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            return RL_OK;
+        }
         if (V == 1 && inplace) {
             // one view: every pass maps a spectrum onto itself (a column tile / a row pair is read
             // completely before it is written), so the whole iteration runs in spec_a -- a third
@@ -440,8 +461,12 @@ struct rl_deconv {
             RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
             return RL_OK;
         }
-        RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
-        RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
+        if (first) {
+            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V));
+        } else {
+            RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
+            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
+        }
         if (fuse_views && V > 1 && wave_private_y()) {
             // views summed in the Fourier domain: one inverse column + one inverse row transform per frame
             RL_TRY(col(sb, sa, nf, COL_HT_FUSED));
@@ -547,8 +572,9 @@ struct rl_deconv {
             } else if (simulate) {
                 rc = simulate_slice(sl, f0, nf);
             }
-            if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf);
-            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) rc = iterate_chunk(f0, nf);
+            const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !use_fused;
+            if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf, !shortcut);
+            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) rc = iterate_chunk(f0, nf, shortcut && i == 0);
         }
         active = nullptr;
         if (ahead) {   // on errors a lane may not have waited for every slice: join the simulation stream too
@@ -642,7 +668,7 @@ int rl_deconv_destroy(rl_deconv* h) {
         hipStreamDestroy(h->sim_stream);
     }
     for (hipEvent_t ev : h->sim_done) hipEventDestroy(ev);
-    void* bufs[] = {h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
+    void* bufs[] = {h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -712,6 +738,33 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         HIP_TRY(e);
         HIP_TRY(e2);
     }
+    // A point-symmetric PSF (every PSF of the reference: symmetric "to 1e-15") has a real spectrum.
+    // Where the imaginary parts are rounding noise (<= 1e-12 of the largest value; in f32 they vanish against
+    // the real parts' own rounding) the wave-private column kernels multiply by the real parts alone: half the
+    // multiplier bytes per column launch.  RLSTED_REAL_PSF=0 keeps the complex multiplier.
+    if (h->wave_private_y() && !(getenv("RLSTED_REAL_PSF") && atoi(getenv("RLSTED_REAL_PSF")) == 0)) {
+        const size_t nz = V * (size_t)h->kx * h->ly;
+        void* re = nullptr;
+        double* stats = nullptr;
+        HIP_TRY(hipMalloc(&re, nz * es + RL_STREAM_SLACK));
+        hipError_t e = hipMalloc((void**)&stats, 2 * sizeof(double));
+        double hs[2] = {1.0, 1.0};
+        if (e == hipSuccess) e = aux_split_real(h->dtype, h->psf_hat, nz, re, stats, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (stats) (void)hipFree(stats);
+        if (e != hipSuccess) {
+            (void)hipFree(re);
+            HIP_TRY(e);
+        }
+        h->psf_hat_imag_ratio = hs[1] > 0 ? hs[0] / hs[1] : 0.0;
+        if (h->psf_hat_imag_ratio <= 1e-12) {
+            h->psf_hat_re = re;
+            h->bytes += nz * es + RL_STREAM_SLACK;
+        } else {
+            (void)hipFree(re);
+        }
+    }
     // H_t(ones), line_sted_tools.py:589-592: sum_v clamp(conv(ones, psf_v))
     HIP_TRY(aux_fill(h->dtype, h->est, h->n_img(), 1.0, ctx->stream));
     {
@@ -722,6 +775,12 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         if (r == RL_OK) r = h->row(ROW_ADJ, 1, h->spec_b, nullptr, nullptr, h->norm, nullptr);
         h->B = keepB;
         RL_TRY(r);
+        // spec_b now holds the column-transformed spectra of H(1), one per view: every frame's first iteration
+        const size_t ones_bytes = V * h->n_spec() * 2 * es;
+        HIP_TRY(hipMalloc(&h->spec_ones, ones_bytes + RL_STREAM_SLACK));
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(h->spec_ones) + ones_bytes, 0, RL_STREAM_SLACK, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h->spec_ones, h->spec_b, ones_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        h->bytes += ones_bytes + RL_STREAM_SLACK;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RL_OK;
@@ -742,6 +801,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
     if (getenv("RLSTED_SIM_AHEAD")) h->sim_ahead = atoi(getenv("RLSTED_SIM_AHEAD")) != 0;
     if (getenv("RLSTED_COL_ORDER")) h->col_order = atoi(getenv("RLSTED_COL_ORDER")) < 1 ? 1 : atoi(getenv("RLSTED_COL_ORDER"));
+    if (getenv("RLSTED_ONES_SHORTCUT")) h->ones_shortcut = atoi(getenv("RLSTED_ONES_SHORTCUT")) != 0;
     if (getenv("RLSTED_FUSED")) h->fused = atoi(getenv("RLSTED_FUSED"));
     if (getenv("RLSTED_FUSED_W")) h->fused_team = std::max(1, atoi(getenv("RLSTED_FUSED_W")));
     if (getenv("RLSTED_FUSED_WGS")) h->fused_wgs = std::max(1, atoi(getenv("RLSTED_FUSED_WGS")));

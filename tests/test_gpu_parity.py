@@ -229,6 +229,9 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
     for stream, inplace, lanes, mb in (('0', '1', '2', '108'), ('7', '1', '2', '108'), ('7', '0', '1', '10'),
                                        ('0', '0', '2', '10'), ('5', '1', '4', '10'), ('2', '0', '3', '20'),
                                        ('0', '1', '1', '100000')):
+        # the streaming column kernel multiplies by the complex PSF spectrum: compare like with like (the
+        # real multiplier of the tiled kernel is a separate compilation with its own fma contraction)
+        monkeypatch.setenv('RLSTED_REAL_PSF', '0')
         monkeypatch.setenv('RLSTED_COL_ORDER', {'10': '3', '100000': '64'}.get(mb, '1'))   # image blocks of the tile order
         monkeypatch.setenv('RLSTED_STREAM', stream)
         monkeypatch.setenv('RLSTED_INPLACE', inplace)
@@ -248,6 +251,15 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
     assert max_rel(ref[:2], d.estimate) < tol
     for key, est in results.items():
         assert max_rel(est, ref) < (2e-6 if dtype == 'f32' else 1e-13), key
+    # default plans: real multiplier for the (point-symmetric) PSF spectrum, first iteration from the shared H(1)
+    for k in ('RLSTED_REAL_PSF', 'RLSTED_STREAM', 'RLSTED_INPLACE', 'RLSTED_LANES', 'RLSTED_CHUNK_MB', 'RLSTED_COL_ORDER'):
+        monkeypatch.delenv(k, raising=False)
+    plan = lib.DeconvPlan(psf, B, 512, 512, dtype=dtype)
+    plan.set_object(objs, 8e11)
+    plan.set_measurement(noisy)
+    plan.iterate(K)
+    assert max_rel(plan.estimate()[:2], d.estimate) < tol
+    assert max_rel(plan.estimate(), ref) < (4e-6 if dtype == 'f32' else 1e-12)
 
 
 @pytest.mark.parametrize('lanes,mb,ahead', [('1', '100000', '0'), ('2', '10', '0'), ('3', '7', '1'), ('2', '10', '1')])
