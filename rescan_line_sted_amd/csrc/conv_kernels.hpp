@@ -337,6 +337,139 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column pass for a long transform L = M * Li on the wave-private core of length Li (M = 2 or 4):
+// one outer decimation-in-time step in registers around M core transforms per column.
+//     x_q[m] = x[M m + q]                      (q = 0 .. M-1: the rows of residue q)
+//     Y_q    = FFT_Li(x_q)                     (the core, one wave per column, exchanges through LDS)
+//     X[k + Li j] = sum_q W_M^(q j) * (W_L^(q k) * Y_q[k])         (radix-M butterfly per register slot)
+//     X *= psf_hat
+//     Z_q[k] = conj(W_L^(q k)) * sum_j conj(W_M)^(q j) * X[k + Li j];   x_q = IFFT_Li(Z_q)
+// Why: a workgroup that holds whole columns of L = 2304 in LDS fits 6 columns (124 KB, one workgroup
+// per CU, 48-byte row segments, barriers between the passes): 0.44 TB/s.  Here LDS holds one residue
+// class at a time -- 8 columns x 576 rows, the L = 576 kernel's 51 KB -- the M core results wait in
+// registers (M * 9 complex values per lane), and the core is the barrier-free wave-private transform.
+// Rows >= ny are zero on the way in and never stored (2048 of 2304: every residue class is the
+// 512-of-576 case of the L = 576 kernel).  COL_PER_IMAGE semantics.
+// Twiddles: p.tw = [core table PassTw<Cfg>][ (M-1) x Li entries W_L^(q k), q = 1 .. M-1 ].
+template <class Cfg, int M, int C, typename T, bool REALP = false, class Sync>
+RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "the core must be a wave-private transform");
+    static_assert(M == 2 || M == 4, "outer radix 2 or 4");
+    constexpr int NP = Cfg::NP, Li = Cfg::L, L = M * Li, LP = LdsSlots<Cfg>::value;
+    constexpr int NT = 64 * C;
+    static_assert((Li * C) % NT == 0, "tile must divide evenly over the workgroup");
+    constexpr int NLD = (Li * C) / NT;
+    using FL = PassInfo<Cfg, false, NP - 1>;
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
+    constexpr int NV = FL::NBM * FL::R;                  // lane-local register slots of one core transform
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    static_assert(NV <= VMAX, "register slots");
+    const int w = tid / 64, lane = tid % 64;
+    const int col0 = bx * C, col = col0 + w;
+    const bool colok = col < p.kx;
+    const size_t img = spec_image_elems(p.ny, p.pitch);
+    const int frame = by / p.V, view = by % p.V;
+    const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
+    cx<T>* __restrict__ out = p.out + (size_t)by * img;
+    const cx<T>* __restrict__ ctw = p.tw + PassTw<Cfg, false, 0>::TOTAL;   // W_L^(q k) at (q - 1) * Li + k
+    LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
+
+    // residue class q of the tile: element e = tid + it*NT <-> (m = e / C, column c = e % C), row M*m + q
+    auto load_class = [&](int q) {
+        cx<T> x[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const int row = M * (e / C) + q, c = e % C;
+            x[it] = mk<T>((T)0, (T)0);
+            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
+        }
+    };
+    auto store_class = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const int row = M * (e / C) + q, c = e % C;
+            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP + view_lds.nat(e / C)];
+        }
+    };
+    // element index (within the core transform) a lane holds in register slot s; s == NV: the tail element
+    auto slot_index = [&](int s) -> int {
+        if (s == NV) return (64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF;
+        return (lane + (s / FL::R) * 64) + (s % FL::R) * FL::NBF;
+    };
+    auto slot_live = [&](int s) -> bool { return s == NV ? true : (lane + (s / FL::R) * 64) < FL::NBF; };
+
+    cx<T> Y[M][NV + 1];   // [q][slot]; slot NV = tail element (unused when the core has none)
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        if (q > 0) sync.wg();          // every wave is done with the previous class in LDS
+        load_class(q);
+        sync.wg();
+        cx<T> v[VMAX];
+        cx<T> tl = mk<T>((T)0, (T)0);
+        if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) Y[q][s] = v[s];
+        Y[q][NV] = tl;
+    }
+    if (colok) {
+        const size_t pcol = ((size_t)view * p.kx + col) * L;
+#pragma unroll
+        for (int s = 0; s <= NV; ++s) {
+            if (s == NV && !FL::TAIL) continue;
+            if (!slot_live(s)) continue;
+            const int k = slot_index(s);
+            cx<T> u[M];
+            u[0] = Y[0][s];
+#pragma unroll
+            for (int q = 1; q < M; ++q) u[q] = cmul(Y[q][s], ctw[(q - 1) * Li + k]);
+            dft<M, false>(u);                                   // u[j] = X[k + Li j]
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if constexpr (REALP) u[j] = scale(u[j], p.psf_hat_re[pcol + k + Li * j]);
+                else u[j] = cmul(u[j], p.psf_hat[pcol + k + Li * j]);
+            }
+            dft<M, true>(u);                                    // u[q] = sum_j conj(W_M)^(q j) X[k + Li j]
+            Y[0][s] = u[0];
+#pragma unroll
+            for (int q = 1; q < M; ++q) {
+                const cx<T> t = ctw[(q - 1) * Li + k];
+                Y[q][s] = cmul(u[q], mk<T>(t.re, -t.im));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        sync.wg();                     // LDS free: the previous class is stored (or the forward transforms are done)
+        if (colok) {
+            cx<T> v[VMAX];
+#pragma unroll
+            for (int s = 0; s < NV; ++s) v[s] = Y[q][s];
+            cx<T> tl = Y[q][NV];
+            run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
+            sync.wave();   // last pass' LDS reads are done before the column is overwritten
+#pragma unroll
+            for (int nb = 0; nb < IL::NB; ++nb) {
+                const int j = lane + nb * 64;
+                if (j < IL::NBF) {
+#pragma unroll
+                    for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
+                }
+            }
+        }
+        sync.wg();
+        store_class(q);
+    }
+}
+
 // -------------------------------- row pass ---------------------------------
 // Two real image rows (2p, 2p+1) ride through one complex transform of length
 // Lx (real row in .re, the next row in .im).  Depending on MODE the body does

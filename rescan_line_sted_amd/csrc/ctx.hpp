@@ -84,10 +84,10 @@ struct rl_ctx {
             *out = it->second;
             return RL_OK;
         }
-        const int count = column ? t->tw_count_col : t->tw_count;
+        const int count = column ? t->tw_count_col[dtype] : t->tw_count;
         const size_t n = 2 * (size_t)(count > 0 ? count : 1);
         std::vector<double> h(n, 0.0);
-        if (count > 0) (column ? t->fill_tw_col : t->fill_tw)(h.data());
+        if (count > 0) (column ? t->fill_tw_col[dtype] : t->fill_tw)(h.data());
         void* dev = nullptr;
         if (dtype == RL_F64) {
             HIP_TRY(hipMalloc(&dev, sizeof(double) * n));

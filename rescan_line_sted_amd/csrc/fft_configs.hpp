@@ -138,6 +138,26 @@ struct ColCfgFor<4608> {
     using type = FftCfg<4608, 288, 16, 16, 18>;
 };
 
+// Long column transforms done as M wave-private core transforms plus one outer radix-M step in registers
+// (conv_kernels.hpp colconv_outer_body), f32 only.  2304 = 4 x 576: LDS holds one residue class of the
+// tile (8 columns x 576 rows = the L = 576 kernel's 51 KB) instead of whole 2304-row columns (124 KB for
+// 6 columns, one workgroup per CU).
+template <int L>
+struct OuterCol {
+    static constexpr bool value = false;
+    using Core = typename CfgFor<64>::Cfg;   // unused
+    static constexpr int M = 2, C = 8;
+};
+#ifndef RL_OUTER_2304
+#define RL_OUTER_2304 1
+#endif
+template <>
+struct OuterCol<2304> {
+    static constexpr bool value = RL_OUTER_2304 != 0;
+    using Core = typename CfgFor<576>::Cfg;
+    static constexpr int M = 4, C = 8;
+};
+
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads
 template <int L>
 constexpr bool cfg_fits() {

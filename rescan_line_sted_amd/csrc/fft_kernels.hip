@@ -104,6 +104,41 @@ __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && M
         colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
 
+// ---- long column transforms on the wave-private core (conv_kernels.hpp colconv_outer_body) ----
+// L = 2304 = 4 x 576, f32: fft_configs.hpp OuterCol<L>.  The f64 kernel of the length stays the
+// workgroup-synchronous one (4 x 9 complex doubles per lane would not fit the register file).
+#ifndef RL_OUTER_MIN_WAVES
+#define RL_OUTER_MIN_WAVES 4
+#endif
+template <int L, int C, bool REALP>
+__global__ void __launch_bounds__(64 * C, RL_OUTER_MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevSync s;
+    using OC = OuterCol<L>;
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
+    if (total % 8 == 0) {   // XCD-contiguous, image-major work order (speed only)
+        const unsigned lin = by * gx + bx;
+        const unsigned w = (lin % 8) * (total / 8) + lin / 8;
+        bx = w % gx;
+        by = w / gx;
+    }
+    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
+}
+template <int L>
+static void fill_outer_twiddles(double* out) {
+    using OC = OuterCol<L>;
+    using Core = typename OC::Core;
+    fill_pass_twiddles<Core>(out);
+    double* dst = out + 2 * PassTw<Core, false, 0>::TOTAL;
+    for (int q = 1; q < OC::M; ++q)
+        for (int k = 0; k < Core::L; ++k) {
+            const long double ang = -6.283185307179586476925286766559005768L * (long double)q * (long double)k / (long double)L;
+            dst[2 * ((q - 1) * Core::L + k)] = (double)__builtin_cosl(ang);
+            dst[2 * ((q - 1) * Core::L + k) + 1] = (double)__builtin_sinl(ang);
+        }
+}
+
 // waves per SIMD requested from the register allocator (f32, wave-private lengths)
 template <int L, int MODE, bool ONEV, typename T>
 constexpr int row_min_waves() {
@@ -344,6 +379,18 @@ static hipError_t launch_row_t(int mode, const void* params, unsigned gx, unsign
 }
 
 static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigned gy, hipStream_t s) {
+    if constexpr (OuterCol<RL_CFG_L>::value) {
+        if (dtype == DT_F32) {
+            using OC = OuterCol<RL_CFG_L>;
+            const ColParams<float>& p = *static_cast<const ColParams<float>*>(params);
+            if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
+            constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
+            const dim3 grid((unsigned)((p.kx + OC::C - 1) / OC::C), gy), block(64 * OC::C);
+            if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds, s, p);
+            else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false>, grid, block, lds, s, p);
+            return hipGetLastError();
+        }
+    }
     return dtype == DT_F32 ? launch_col_t<kC32, float>(params, gx, gy, s)
                            : launch_col_t<kC64, double>(params, gx, gy, s);
 }
@@ -386,10 +433,28 @@ static hipError_t prepare() {
     return hipSuccess;
 }
 
+// (the length is a template parameter: this file is compiled once per length, and equally named entities of
+// different translation units would be merged by the linker)
+template <int L, bool OUTER>
+struct OuterTw {   // column twiddle table of the f32 kernel: the outer-decimation kernel's, where the length has one
+    static constexpr int count = PassTw<typename ColCfgFor<L>::type, false, 0>::TOTAL;
+    static void fill(double* out) { fill_pass_twiddles<typename ColCfgFor<L>::type>(out); }
+};
+template <int L>
+struct OuterTw<L, true> {
+    using OC = OuterCol<L>;
+    static constexpr int count = PassTw<typename OC::Core, false, 0>::TOTAL + (OC::M - 1) * OC::Core::L;
+    static void fill(double* out) { fill_outer_twiddles<L>(out); }
+};
+
 const KernelTable* RL_TABLE_FN() {
-    static const KernelTable t = {Cfg::L, Cfg::T, {kC32, kC64}, {kQ32, kQ64}, WavePrivate<CCfg>::value ? 1 : 0,
+    constexpr bool OUTER = OuterCol<RL_CFG_L>::value;
+    constexpr int WP = WavePrivate<CCfg>::value ? 1 : 0;
+    static const KernelTable t = {Cfg::L, Cfg::T, {OUTER ? OuterCol<RL_CFG_L>::C : kC32, kC64}, {kQ32, kQ64},
+                                  {OUTER ? 1 : WP, WP}, {WP, WP},
                                   PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
-                                  PassTw<CCfg, false, 0>::TOTAL, fill_pass_twiddles<CCfg>, launch_col, launch_row, prepare,
+                                  {OuterTw<RL_CFG_L, OUTER>::count, PassTw<CCfg, false, 0>::TOTAL},
+                                  {OuterTw<RL_CFG_L, OUTER>::fill, fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,
                                   WavePrivate<CCfg>::value ? launch_col_stream : nullptr,
                                   WavePrivate<Cfg>::value ? launch_row_stream : nullptr,
                                   (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) ? launch_fused : nullptr};

@@ -20,11 +20,13 @@ struct KernelTable {
     int T;            // threads per transform
     int C[2];         // spectrum columns per workgroup in the column kernel, per dtype
     int Q[2];         // row pairs per workgroup in the row kernels, per dtype
-    int psf_transposed;   // column kernel reads psf_hat as [view][Kx][L] (wave-private transforms)
+    // per dtype (the f32 and f64 column kernels of a length may be different kernels):
+    int psf_transposed[2];   // column kernel reads psf_hat as [view][Kx][L] (one wave per column)
+    int col_multi[2];        // the multi-view column modes (COL_H_MULTI / COL_HT_SUM) exist
     int tw_count;         // complex entries of the per-pass twiddle table (fft_core.hpp PassTw), row kernels
     void (*fill_tw)(double* out);   // host: writes 2*tw_count doubles (re, im interleaved)
-    int tw_count_col;     // the same for the column kernels (their geometry may differ: fft_configs.hpp ColCfgFor)
-    void (*fill_tw_col)(double* out);
+    int tw_count_col[2];  // the same for the column kernels (their geometry may differ: fft_configs.hpp ColCfgFor)
+    void (*fill_tw_col[2])(double* out);
     // params: pointer to ColParams<T> / RowParams<T> of the matching dtype
     hipError_t (*launch_col)(int dtype, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);
     hipError_t (*launch_row)(int dtype, int mode, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);

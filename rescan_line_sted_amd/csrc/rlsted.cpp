@@ -237,7 +237,8 @@ struct rl_deconv {
     size_t n_spec() const { return spec_image_elems(ny, pitch); }   // complex elements of one spectrum image
 
     enum ColKind { COL_H, COL_HT_VIEW, COL_HT_FUSED };
-    bool wave_private_y() const { return ty->psf_transposed != 0; }   // multi-view modes exist there only
+    bool wave_private_y() const { return ty->col_multi[dtype] != 0; }    // the multi-view column modes exist
+    bool psf_transposed() const { return ty->psf_transposed[dtype] != 0; }   // psf_hat is [view][Kx][Ly]
     template <typename T>
     int col_t(const void* in, void* out, int frames, ColKind kind) {
         ColParams<T> p;
@@ -410,7 +411,10 @@ struct rl_deconv {
         const double budget_mb = getenv("RLSTED_CHUNK_MB") ? atof(getenv("RLSTED_CHUNK_MB")) : (lanes > 1 ? 108.0 : 288.0);
         const double specs = (V == 1 && inplace) ? 1.0 : 1.0 + V;   // spectra alive in an iteration
         const double per_frame = (specs * 2.0 * n_spec() + (1.0 + V) * n_img()) * esize(dtype);
-        int c = (int)(budget_mb * 1048576.0 / per_frame);
+        // Frames of 32 MB and more (2048^2 up) do not live in the Infinity Cache whatever the slice: there the slice
+        // only has to fill the chip -- ~1 GB per slice measured best at 2048^2 (point 658 -> 713, 4 views 180 -> 192
+        // frames/s over 2-frame / 1-frame slices).
+        int c = (int)((!getenv("RLSTED_CHUNK_MB") && per_frame >= 32.0 * 1048576.0 ? 1024.0 : budget_mb) * 1048576.0 / per_frame);
         // many views: at least 8 frames per slice when no budget was given -- fewer leave the column
         // kernels (37 workgroups per 512^2 frame) too small to fill the chip (6 / 8 views: +10 % / +7 %)
         if (!getenv("RLSTED_CHUNK_MB") && c < 8 && per_frame * 8.0 <= 300.0 * 1048576.0) c = 8;
@@ -731,7 +735,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         HIP_TRY(hipMalloc(&s1, V * h->py * h->kx * 16));
         HIP_TRY(hipMemcpyAsync(psf_dev, psfs, np * 8, hipMemcpyHostToDevice, ctx->stream));
         hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat, h->V, h->py, h->px,
-                                        h->ly, h->lx, h->kx, h->pitch, h->ty->psf_transposed, ctx->stream);
+                                        h->ly, h->lx, h->kx, h->pitch, h->ty->psf_transposed[h->dtype], ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
         hipFree(psf_dev);
         hipFree(s1);
@@ -742,7 +746,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     // Where the imaginary parts are rounding noise (<= 1e-12 of the largest value; in f32 they vanish against
     // the real parts' own rounding) the wave-private column kernels multiply by the real parts alone: half the
     // multiplier bytes per column launch.  RLSTED_REAL_PSF=0 keeps the complex multiplier.
-    if (h->wave_private_y() && !(getenv("RLSTED_REAL_PSF") && atoi(getenv("RLSTED_REAL_PSF")) == 0)) {
+    if (h->psf_transposed() && !(getenv("RLSTED_REAL_PSF") && atoi(getenv("RLSTED_REAL_PSF")) == 0)) {
         const size_t nz = V * (size_t)h->kx * h->ly;
         void* re = nullptr;
         double* stats = nullptr;

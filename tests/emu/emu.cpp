@@ -221,6 +221,50 @@ int emu_row_f32(int L, int mode, const float* spec_in, float* spec_out, const fl
     DISPATCH_L(L, (row_t<LL, float>(mode, spec_in, spec_out, src, dst, norm, scale, ny, nx, pitch, V, gy)))
 }
 
+// colconv_outer_body (long column transforms on a wave-private core): L = M * Li, Li in {256, 576}.
+// psf_hat: complex [V][kx][L] (transposed layout), or -- real_psf -- its real parts [V][kx][L].
+}  // extern "C"
+template <class Core, int M, typename T>
+static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
+                       int in_sb, int in_sv) {
+    constexpr int C = 8, L = M * Core::L;
+    constexpr int n_core = PassTw<Core, false, 0>::TOTAL;
+    std::vector<double> h(2 * (size_t)(n_core + (M - 1) * Core::L));
+    fill_pass_twiddles<Core>(h.data());
+    for (int q = 1; q < M; ++q)
+        for (int k = 0; k < Core::L; ++k) {
+            const long double a = -6.283185307179586476925286766559005768L * (long double)q * (long double)k / (long double)L;
+            h[2 * (size_t)(n_core + (q - 1) * Core::L + k)] = (double)cosl(a);
+            h[2 * (size_t)(n_core + (q - 1) * Core::L + k) + 1] = (double)sinl(a);
+        }
+    std::vector<cx<T>> tw(h.size() / 2);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = mk<T>((T)h[2 * i], (T)h[2 * i + 1]);
+    ColParams<T> p;
+    p.in = reinterpret_cast<const cx<T>*>(in);
+    p.out = reinterpret_cast<cx<T>*>(out);
+    p.psf_hat = real_psf ? nullptr : reinterpret_cast<const cx<T>*>(psf_hat);
+    p.psf_hat_re = real_psf ? psf_hat : nullptr;
+    p.tw = tw.data();
+    p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
+    p.mode = COL_PER_IMAGE; p.images = frames * V; p.order = 1;
+    run_grid((kx + C - 1) / C, frames * V, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
+             [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                 if (real_psf) colconv_outer_body<Core, M, C, T, true>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 else colconv_outer_body<Core, M, C, T, false>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+             });
+    return 0;
+}
+extern "C" {
+int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
+                      int pitch, int V, int frames, int in_sb, int in_sv) {
+    using C256 = CfgFor<256>::Cfg;
+    using C576 = CfgFor<576>::Cfg;
+    if (Li == 256 && M == 4) return col_outer_t<C256, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    if (Li == 256 && M == 2) return col_outer_t<C256, 2, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    if (Li == 576 && M == 4) return col_outer_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    return -2;
+}
+
 // host build of the device Poisson sampler (philox_poisson.hpp)
 int emu_poisson(const double* lam, int n, unsigned long long seed, unsigned image, double* out) {
     for (int i = 0; i < n; ++i) out[i] = philox_poisson(lam[i], seed, image, (unsigned)i);

@@ -358,3 +358,30 @@ def test_streaming_bodies_l576_f32(emu):
         emu.emu_set_stream(0)
     assert np.array_equal(streamed, tiled)
     assert max_rel(streamed, d.estimate) < 2e-5
+
+
+# ------------------------------------------------- long column transforms on the wave-private core
+@pytest.mark.parametrize('Li,M,ny,kx,real_psf', [(256, 4, 900, 11, 0), (256, 2, 437, 8, 1), (576, 4, 2048, 9, 0),
+                                                   (576, 4, 2001, 3, 1)])
+def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
+    """colconv_outer_body: L = M * Li as M core transforms plus one radix-M step in registers (the f32
+    column kernel of L = 2304 = 4 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat), rows < ny."""
+    if emu.emu_spec_blocked():
+        pytest.skip('row-major spectra only')
+    L, V, frames = M * Li, 2, 1
+    pitch = (kx + 7) // 8 * 8
+    rng = np.random.default_rng(Li + M + ny)
+    x = np.zeros((frames, ny, pitch), dtype=np.complex128)
+    x[:, :, :kx] = rng.standard_normal((frames, ny, kx)) + 1j * rng.standard_normal((frames, ny, kx))
+    ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
+    out = np.zeros((frames * V, ny, pitch), dtype=np.complex128)
+    psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
+    rc = emu.emu_col_outer_f64(Li, M, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, 1, 0)
+    assert rc == 0
+    full = np.zeros((frames, L, kx), dtype=np.complex128)
+    full[:, :ny] = x[:, :, :kx]
+    spec = np.fft.fft(full, axis=1)                                   # (frames, L, kx)
+    for f in range(frames):
+        for v in range(V):
+            ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L     # the kernels leave the 1/L to psf_hat's scale
+            assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
