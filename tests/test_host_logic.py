@@ -129,16 +129,16 @@ def test_deconvolver_surface_matches_reference(tmp_path):
 
 
 def test_pmc_traffic_json_is_what_the_tool_makes_of_the_committed_counter_files(tmp_path):
-    """profiles/r01/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from
+    """profiles/r02/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from
     the committed rocprofv3 counter files with tools/pmc_traffic.py."""
     import json
     import subprocess
     import sys
-    prof = os.path.join(ROOT, 'profiles', 'r01')
+    prof = os.path.join(ROOT, 'profiles', 'r02')
     committed = json.load(open(os.path.join(prof, 'pmc_traffic.json')))
     out = tmp_path / 'traffic.json'
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'),
-                           os.path.join(prof, 'pmc_fetch_size_v7.csv'), os.path.join(prof, 'pmc_write_size_v7.csv'),
+                           os.path.join(prof, 'pmc_fetch_size.csv'), os.path.join(prof, 'pmc_write_size.csv'),
                            str(out), str(committed['frames_per_launch'])], stdout=subprocess.DEVNULL)
     again = json.load(open(out))
     assert again == committed

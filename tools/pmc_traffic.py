@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 PMC passes over bench.py into profiles/rNN/pmc_traffic.json.
+"""Turn two rocprofv3 PMC passes over bench.py into profiles/rNN/pmc_traffic.json (fabric bytes per launch).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- \
@@ -54,7 +54,9 @@ def main():
            'batch': batch, 'frames_per_launch': fl, 'dtype': 'f32', 'shape': [512, 512], 'n_psf': 1}
     for key in sorted(set(fetch) | set(write)):
         f, w = fetch.get(key, 0.0), write.get(key, 0.0)
-        res[key] = {'hbm_bytes_per_launch': 2 * f * 1024 + w * 1024, 'fetch_kb_reported': f, 'write_kb_reported': w}
+        # FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: Infinity Cache hits are counted too, so
+        # this is fabric traffic (what leaves the XCD's L2), not bytes that reached HBM
+        res[key] = {'fabric_bytes_per_launch': 2 * f * 1024 + w * 1024, 'fetch_kb_reported': f, 'write_kb_reported': w}
     if 'colconv' in res:   # the H and H_t column passes are the same kernel
         res['colconv_H'] = res['colconv_Ht'] = res['colconv']
     if 'rowpass_FWD' in res:
@@ -62,7 +64,7 @@ def main():
         res['_calibration'] = {'rowpass_FWD_must_read_bytes': fl * 512 * 512 * 4,
                                'rowpass_FWD_fetch_reported_bytes': res['rowpass_FWD']['fetch_kb_reported'] * 1024}
     json.dump(res, open(sys.argv[3], 'w'), indent=1)
-    print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in res.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v}))
+    print(json.dumps({k: v['fabric_bytes_per_launch'] for k, v in res.items() if isinstance(v, dict) and 'fabric_bytes_per_launch' in v}))
 
 
 if __name__ == '__main__':
