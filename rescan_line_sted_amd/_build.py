@@ -61,6 +61,25 @@ def jobs():
     return [j for j in out if os.path.exists(j[1])]
 
 
+VARIANTS = {   # study builds: librlsted_<name>.so beside the product library (python -m ..._build --variant NAME)
+    'q16': ['-DRL_SPEC_QUANT=1'],     # spectra rounded to IEEE half on their way to memory (BASELINE config 5 study)
+    'qbf16': ['-DRL_SPEC_QUANT=2'],   # ... to bfloat16
+}
+
+
+def build_variant(name, verbose=False):
+    """A study build of the whole library with extra defines, objects under build/obj_<name>/."""
+    global OBJ, LIB, DEVICE
+    keep = (OBJ, LIB, DEVICE)
+    try:
+        OBJ = os.path.join(ROOT, 'build', 'obj_' + name)
+        LIB = os.path.join(LIBDIR, 'librlsted_%s.so' % name)
+        DEVICE = DEVICE + VARIANTS[name]
+        return build(force=False, verbose=verbose)
+    finally:
+        OBJ, LIB, DEVICE = keep
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -85,4 +104,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--variant' in sys.argv:
+        print(build_variant(sys.argv[sys.argv.index('--variant') + 1], verbose=True))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))

@@ -40,6 +40,30 @@ RL_HD float rl_div(float a, float b) {
 RL_HD double rl_div(double a, double b) { return a / b; }
 
 // ---------------------------------------------------------------------------
+// Storage-precision STUDY builds (BASELINE config 5: "fp32 vs fp16 convolve, tolerance study"):
+// RL_SPEC_QUANT = 1 rounds every spectrum value to IEEE half precision on its way to global memory (scaled
+// by the launch's power of two `qscale`, which brings the spectrum's DC term -- the bound of every
+// coefficient of a non-negative image -- to 2^14), RL_SPEC_QUANT = 2 to bfloat16 (f32's range: no scale).
+// The values are still stored as f32: the build measures what 16-bit spectrum storage between the row
+// and the column kernels would do to the results, not its bandwidth.  0 (every product build): identity.
+#ifndef RL_SPEC_QUANT
+#define RL_SPEC_QUANT 0
+#endif
+template <typename T>
+RL_HD cx<T> rl_spec_round(cx<T> v, float qscale) {
+#if RL_SPEC_QUANT == 1 && defined(__HIP_DEVICE_COMPILE__)
+    const float inv = 1.0f / qscale;   // qscale is a power of two: exact
+    return mk<T>((T)((float)(_Float16)((float)v.re * qscale) * inv), (T)((float)(_Float16)((float)v.im * qscale) * inv));
+#elif RL_SPEC_QUANT == 2 && defined(__HIP_DEVICE_COMPILE__)
+    (void)qscale;
+    return mk<T>((T)(float)(__bf16)(float)v.re, (T)(float)(__bf16)(float)v.im);
+#else
+    (void)qscale;
+    return v;
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // Layout of a row-transformed spectrum image in global memory (ny rows x pitch columns of
 // complex T, pitch a multiple of 8): plain row-major rows, or -- RL_SPEC_BLOCKED -- blocked as
 // [row pair][8-column block][row parity][8 columns], so that the 2 x 8 elements two consecutive
@@ -87,6 +111,7 @@ struct ColParams {
     // psf_hat ([view][kx][L]); used by the REALP instantiations of the wave-private column kernel
     // (half the multiplier bytes, a real x complex product).  nullptr: the complex multiplier.
     const T* psf_hat_re = nullptr;
+    float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
 template <class Cfg, int C, typename T, class Sync>
@@ -149,7 +174,7 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
 #pragma unroll
             for (int r = 0; r < IL::R; ++r) {
                 const int i = j + r * IL::NBF;
-                if (j < IL::NBF && colok && i < p.ny) out[spec_off(i, col, p.pitch)] = v[nb * IL::R + r];
+                if (j < IL::NBF && colok && i < p.ny) out[spec_off(i, col, p.pitch)] = rl_spec_round(v[nb * IL::R + r], p.qscale);
             }
         }
     }
@@ -215,7 +240,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
             const int row = e / C, c = e % C;
-            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP + view_lds.nat(row)];
+            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(row)], p.qscale);
         }
     };
     // v, tl *= psf_hat[view] column (register layout of the last forward pass)
@@ -397,7 +422,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
             const int row = M * (e / C) + q, c = e % C;
-            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP + view_lds.nat(e / C)];
+            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(e / C)], p.qscale);
         }
     };
     // element index (within the core transform) a lane holds in register slot s; s == NV: the tail element
@@ -498,6 +523,7 @@ struct RowParams {
     // from estimate = 1 (ref:522), whose H(est) is the same for every frame: its V column-transformed
     // spectra are computed once per plan and every frame's ROW_RATIO reads them.
     int in_mod = 0;
+    float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
 // ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.
@@ -688,8 +714,8 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             const int k = t + it * TT;
             if (k <= L / 2) {
                 const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
-                if (ok0) so[spec_off(r0, k, p.pitch)] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
-                if (ok1) so[spec_off(r1, k, p.pitch)] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+                if (ok0) so[spec_off(r0, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
+                if (ok1) so[spec_off(r1, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
             }
         }
         rl_stamp(sync, 5);
@@ -856,7 +882,7 @@ RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>
             for (int it = 0; it < NLD; ++it) {
                 const int e = tid + it * NT;
                 const int row = e / C, c = e % C;
-                if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP + view_lds.nat(row)];
+                if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(row)], p.qscale);
             }
         }
         rl_stamp(sync, 7);
@@ -1022,8 +1048,8 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
         const int kk = tl_ + it * 64;
         if (kk <= L / 2) {
             const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
-            so0[lane_so + it * SPEC_PAIR_STEP64] = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));
-            if (ok1) so1[lane_so + it * SPEC_PAIR_STEP64] = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));
+            so0[lane_so + it * SPEC_PAIR_STEP64] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
+            if (ok1) so1[lane_so + it * SPEC_PAIR_STEP64] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
         }
     }
     rl_stamp(sync, 5);

@@ -76,6 +76,9 @@ struct rl_deconv {
     void* spec_a = nullptr;    // [B] spectrum images (layout: conv_kernels.hpp spec_off)
     void* spec_b = nullptr;    // [B*V] spectrum images
     void* spec_ones = nullptr; // [V] column-transformed spectra of H(estimate = 1): the same for every frame (ref:522)
+    // storage-precision study builds (conv_kernels.hpp RL_SPEC_QUANT): powers of two that bring the DC term of an
+    // estimate-type / ratio-type spectrum to 2^14 (RLSTED_Q_EXP_EST / RLSTED_Q_EXP_RATIO = log2 of the DC bound)
+    float q_est = 1.0f, q_ratio = 1.0f;
     bool ones_shortcut = true; // first iteration reads spec_ones instead of transforming a frame of ones (RLSTED_ONES_SHORTCUT=0: off)
     void* obj = nullptr;       // [B][ny][nx]
     void* noiseless = nullptr; // [B*V][ny][nx]
@@ -246,6 +249,7 @@ struct rl_deconv {
         p.out = (cx<T>*)out;
         p.psf_hat = (const cx<T>*)psf_hat;
         p.psf_hat_re = (const T*)psf_hat_re;
+        p.qscale = kind == COL_H ? q_est : q_ratio;
         p.tw = (const cx<T>*)twy;
         p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V;
         unsigned gy = (unsigned)(frames * V);
@@ -298,6 +302,7 @@ struct rl_deconv {
               const void* scale, int views, int in_mod = 0) {
         RowParams<T> p;
         p.in_mod = in_mod;
+        p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
         p.src = (const T*)src;
@@ -446,7 +451,13 @@ struct rl_deconv {
     }
     // first: the iteration starts from estimate = 1 (just filled): H(estimate) is spec_ones for every frame, so the
     // column pass of H is skipped and ROW_RATIO reads the shared spectra (bit for bit what the pass would write)
-    int iterate_chunk(int f0, int nf, bool first = false) {
+    int iterate_chunk(int f0, int nf, bool first = false, bool from_ones = false) {
+        // (study builds: the ratio of the iteration that starts from estimate = 1 is measurement / H(1), data scale)
+        struct ScaleGuard {
+            float& q; float keep;
+            ~ScaleGuard() { q = keep; }
+        } scale_guard{q_ratio, q_ratio};
+        if (from_ones) q_ratio = q_est;
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         if (first && V == 1 && inplace) {
@@ -578,7 +589,7 @@ struct rl_deconv {
             }
             const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !use_fused;
             if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf, !shortcut);
-            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) rc = iterate_chunk(f0, nf, shortcut && i == 0);
+            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) rc = iterate_chunk(f0, nf, shortcut && i == 0, restart && i == 0);
         }
         active = nullptr;
         if (ahead) {   // on errors a lane may not have waited for every slice: join the simulation stream too
@@ -774,10 +785,20 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     {
         const int keepB = h->B;
         h->B = 1;
+        // (study builds: the spectra of a frame of ones have DC = pixels x sum(psf), not the data's)
+        const float keep_q = h->q_est;
+        double psf_sum = 1.0;
+        for (size_t v = 0; v < V; ++v) {
+            double t = 0.0;
+            for (size_t i = 0; i < (size_t)h->py * h->px; ++i) t += psfs[v * h->py * h->px + i];
+            psf_sum = std::max(psf_sum, t);
+        }
+        if (getenv("RLSTED_Q_EXP_EST")) h->q_est = std::ldexp(1.0f, 14 - (int)std::ceil(std::log2((double)h->n_img() * psf_sum)) - 1);
         int r = h->row(ROW_FWD, 1, nullptr, h->spec_a, h->est, nullptr, nullptr);
         if (r == RL_OK) r = h->col(h->spec_a, h->spec_b, 1, true);
         if (r == RL_OK) r = h->row(ROW_ADJ, 1, h->spec_b, nullptr, nullptr, h->norm, nullptr);
         h->B = keepB;
+        h->q_est = keep_q;
         RL_TRY(r);
         // spec_b now holds the column-transformed spectra of H(1), one per view: every frame's first iteration
         const size_t ones_bytes = V * h->n_spec() * 2 * es;
@@ -805,6 +826,8 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
     if (getenv("RLSTED_SIM_AHEAD")) h->sim_ahead = atoi(getenv("RLSTED_SIM_AHEAD")) != 0;
     if (getenv("RLSTED_COL_ORDER")) h->col_order = atoi(getenv("RLSTED_COL_ORDER")) < 1 ? 1 : atoi(getenv("RLSTED_COL_ORDER"));
+    if (getenv("RLSTED_Q_EXP_EST")) h->q_est = std::ldexp(1.0f, 14 - atoi(getenv("RLSTED_Q_EXP_EST")));
+    if (getenv("RLSTED_Q_EXP_RATIO")) h->q_ratio = std::ldexp(1.0f, 14 - atoi(getenv("RLSTED_Q_EXP_RATIO")));
     if (getenv("RLSTED_ONES_SHORTCUT")) h->ones_shortcut = atoi(getenv("RLSTED_ONES_SHORTCUT")) != 0;
     if (getenv("RLSTED_FUSED")) h->fused = atoi(getenv("RLSTED_FUSED"));
     if (getenv("RLSTED_FUSED_W")) h->fused_team = std::max(1, atoi(getenv("RLSTED_FUSED_W")));
