@@ -376,6 +376,10 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 // registers (M * 9 complex values per lane), and the core is the barrier-free wave-private transform.
 // Rows >= ny are zero on the way in and never stored (2048 of 2304: every residue class is the
 // 512-of-576 case of the L = 576 kernel).  COL_PER_IMAGE semantics.
+// (Tried and measured slower, 907 vs 569 us per 16-frame launch at one workgroup per CU: decimation in frequency
+// over M blocks of contiguous rows with the core transforms chained forward -> multiply -> inverse in registers.
+// It loads all M blocks before the first transform and keeps all M x 9 values live through every core transform;
+// the residue-class form below interleaves loads and transforms and lets the live set grow with them.)
 // Twiddles: p.tw = [core table PassTw<Cfg>][ (M-1) x Li entries W_L^(q k), q = 1 .. M-1 ].
 template <class Cfg, int M, int C, typename T, bool REALP = false, class Sync>
 RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {

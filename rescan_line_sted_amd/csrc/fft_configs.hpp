@@ -151,11 +151,16 @@ struct OuterCol {
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
 #endif
+#ifndef RL_OUTER_C
+#define RL_OUTER_C 8      // columns (= waves) per workgroup of the outer-decimation column kernel.  Measured at 2048^2,
+                          // 16-frame launches: 4 / 8 / 16 columns 565 / 611 / 599 us, one or two workgroups per CU
+                          // (RL_OUTER_MIN_WAVES 2 / 4) 569 / 611 us: the kernel's time does not move with its geometry
+#endif
 template <>
 struct OuterCol<2304> {
     static constexpr bool value = RL_OUTER_2304 != 0;
     using Core = typename CfgFor<576>::Cfg;
-    static constexpr int M = 4, C = 8;
+    static constexpr int M = 4, C = RL_OUTER_C;
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

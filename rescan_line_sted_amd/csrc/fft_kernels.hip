@@ -428,6 +428,12 @@ static hipError_t prepare() {
         if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, true>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double, true>, col_lds_bytes<kC64, double>())) != hipSuccess) return e;
     }
+    if constexpr (OuterCol<RL_CFG_L>::value) {
+        using OC = OuterCol<RL_CFG_L>;
+        constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds)) != hipSuccess) return e;
+    }
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
     return hipSuccess;
