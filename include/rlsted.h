@@ -116,8 +116,17 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
 /* Device address of a plan buffer for zero-copy hand-off (e.g. the RCCL gather
  * of final estimates): which = 0 estimate [batch][ny][nx], 1 measurement, 2
  * noiseless [batch][n_psf][ny][nx], 3 object.  The buffer stays owned by the
- * plan; *dtype = RL_F32 / RL_F64 element type.  Synchronise the context first. */
+ * plan; *dtype = RL_F32 / RL_F64 element type.  Synchronise the context first.
+ * The allocation extends 16 KiB past n_elements (zeroed slack that the row kernels' unconditional 64-lane
+ * loads may read and discard): never write there, never assume the next buffer starts right behind. */
 int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements, int* dtype);
+
+/* Convolution strategy the plan chose for its PSF set: separable != 0: every view
+ * is rank 1 (p = u v^T; the 0 / 90 degree line PSFs) and small, H / H_t run as direct row + column stencils;
+ * otherwise the FFT path, with real_psf_spectrum != 0 when the (point-symmetric) PSFs' spectra are real and
+ * the column kernels multiply by their real parts alone; fused_rl != 0: RLSTED_FUSED selected the persistent
+ * XCD-resident Richardson-Lucy kernel.  Any of the pointers may be NULL.            */
+int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl);
 
 /* Plan geometry: frames per plan, views per frame, image shape.                */
 int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx);

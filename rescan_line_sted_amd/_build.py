@@ -55,6 +55,7 @@ def jobs():
     out.append((os.path.join(OBJ, 'comm.o'), os.path.join(CSRC, 'comm.cpp'), ['-x', 'hip'] + DEVICE))
     out.append((os.path.join(OBJ, 'psf_api.o'), os.path.join(CSRC, 'psf_api.cpp'), ['-x', 'hip'] + DEVICE))
     out.append((os.path.join(OBJ, 'quality_kernels.o'), os.path.join(CSRC, 'quality_kernels.hip'), DEVICE))
+    out.append((os.path.join(OBJ, 'sep_kernels.o'), os.path.join(CSRC, 'sep_kernels.hip'), DEVICE))
     out.append((os.path.join(OBJ, 'fig3_kernels.o'), os.path.join(CSRC, 'fig3_kernels.hip'), DEVICE))
     out.append((os.path.join(OBJ, 'quality_api.o'), os.path.join(CSRC, 'quality_api.cpp'), ['-x', 'hip'] + DEVICE))
     out.append((os.path.join(OBJ, 'gauss_fit.o'), os.path.join(CSRC, 'gauss_fit.cpp'), ['-ffp-contract=off']))

@@ -48,6 +48,7 @@ PROTOTYPES = {
     'rl_deconv_time_kernels': (_i, [_vp, _i, _dp]),
     'rl_deconv_time_cycle': (_i, [_vp, _i, _i, _c.c_uint64, _dp, _dp, _dp]),
     'rl_deconv_device_ptr': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
+    'rl_deconv_strategy': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_deconv_dims': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_batch_run': (_i, [_vp, _vp, _i, _i, _i, _dp]),
     'rl_comm_unique_id': (_i, [_vp]),
@@ -158,6 +159,11 @@ class DeconvPlan:
         check(lib.rl_deconv_info(self.handle, ctypes.byref(ly), ctypes.byref(lx), ctypes.byref(pitch),
                                  ctypes.byref(nbytes)))
         return {'ly': ly.value, 'lx': lx.value, 'pitch': pitch.value, 'device_bytes': nbytes.value}
+
+    def strategy(self):
+        a, b, c = _i(), _i(), _i()
+        check(lib.rl_deconv_strategy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {'separable': bool(a.value), 'real_psf_spectrum': bool(b.value), 'fused_rl': bool(c.value)}
 
     def set_object(self, obj, total_brightness=None):
         obj = as_f64(obj).reshape(self.B, self.ny, self.nx)

@@ -20,6 +20,7 @@
 #include "kernel_table.hpp"
 #include "ctx.hpp"
 #include "fused_rl.hpp"
+#include "sep_kernels.hpp"
 
 using namespace rl;
 
@@ -121,6 +122,64 @@ struct rl_deconv {
     long iterations = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_iter_ms = 0, last_sim_ms = 0;
+
+    // ---- separable strategy (sep_kernels.hip): every view rank 1 (p = u v^T) and small -> direct row + column stencils
+    // instead of the FFT path.  RLSTED_SEP: 0 never, 1 (default) when py + px <= RLSTED_SEP_MAX_TAPS (16: the measured
+    // crossover, profiles/r02/separable_vs_fft.json -- the FFT path's cost does not depend on the PSF size), 2 whenever rank 1.
+    bool sep = false;
+    void *sep_u = nullptr, *sep_v = nullptr;   // [V][py], [V][px] in the plan's dtype
+    void *sep_uf = nullptr, *sep_vf = nullptr; // flipped, zero padded to multiples of 8: the one-kernel form's taps
+    bool sep_one = false;                      // both passes in one kernel (RLSTED_SEP_ONE, see deconv_build)
+    int sep2d_(int mode, const void* in, const void* aux, const void* nrm, void* dst, int frames) {
+        const bool multi = mode == SEP_SUM_ || mode == SEP_UPDATE_;
+        for (int f0 = 0; f0 < frames; f0 += 65535) {
+            const int n = std::min(65535, frames - f0);
+            const size_t img = n_img() * esize(dtype), in_off = (size_t)f0 * (multi ? V : 1) * img, out_off = (size_t)f0 * (multi ? 1 : V) * img;
+            HIP_TRY(sep2d(dtype, mode, (const char*)in + in_off, sep_uf, sep_vf, aux ? (const char*)aux + out_off : nullptr, nrm,
+                          (char*)dst + out_off, n, ny, nx, py, px, V, cur()));
+        }
+        return RL_OK;
+    }
+    void* sep_tmp() const { return spec_b; }    // row-pass results [B*V][ny][nx] (the spectrum buffer is free in this mode)
+    int sep_rows_(const void* in, void* out, int images, int in_div) {
+        for (int i0 = 0; i0 < images; i0 += 65535 / V * V) {   // grid.z pieces of whole frames
+            const int n = std::min(65535 / V * V, images - i0);
+            HIP_TRY(sep_rows(dtype, (const char*)in + (size_t)(i0 / in_div) * n_img() * esize(dtype),
+                             (char*)out + (size_t)i0 * n_img() * esize(dtype), sep_v, n, ny, nx, px, V, in_div, cur()));
+        }
+        return RL_OK;
+    }
+    // mode, tmp [count*(multi ? V : 1)] -> dst [count]; aux: the measurement for SEP_RATIO_
+    int sep_cols_(int mode, const void* tmp, const void* aux, const void* nrm, void* dst, int count) {
+        const bool multi = mode == SEP_SUM_ || mode == SEP_UPDATE_;
+        const int step = multi ? 65535 : 65535 / V * V;
+        for (int i0 = 0; i0 < count; i0 += step) {
+            const int n = std::min(step, count - i0);
+            const size_t in_off = (size_t)i0 * (multi ? V : 1) * n_img() * esize(dtype), out_off = (size_t)i0 * n_img() * esize(dtype);
+            HIP_TRY(sep_cols(dtype, mode, (const char*)tmp + in_off, sep_u, aux ? (const char*)aux + out_off : nullptr, nrm,
+                             (char*)dst + out_off, n, ny, nx, py, V, cur()));
+        }
+        return RL_OK;
+    }
+    // H of nf frames: x [nf] -> out [nf*V] (clamped)
+    int sep_forward(const void* x, void* out, int nf) {
+        if (sep_one) return sep2d_(SEP_STORE_, x, nullptr, nullptr, out, nf);
+        RL_TRY(sep_rows_(x, sep_tmp(), nf * V, V));
+        return sep_cols_(SEP_STORE_, sep_tmp(), nullptr, nullptr, out, nf * V);
+    }
+    int sep_iterate(int f0, int nf) {   // ref:520-531
+        void* e = off(est, (size_t)f0 * n_img());
+        void* ratio = off(scratch, (size_t)f0 * V * n_img());
+        void* tmp = off(sep_tmp(), (size_t)f0 * V * n_img());
+        if (sep_one) {
+            RL_TRY(sep2d_(SEP_RATIO_, e, off(meas, (size_t)f0 * V * n_img()), nullptr, ratio, nf));
+            return sep2d_(SEP_UPDATE_, ratio, nullptr, norm, e, nf);
+        }
+        RL_TRY(sep_rows_(e, tmp, nf * V, V));
+        RL_TRY(sep_cols_(SEP_RATIO_, tmp, off(meas, (size_t)f0 * V * n_img()), nullptr, ratio, nf * V));
+        RL_TRY(sep_rows_(ratio, tmp, nf * V, 1));
+        return sep_cols_(SEP_UPDATE_, tmp, nullptr, norm, e, nf);
+    }
 
     // ---- fused Richardson-Lucy loop (fused_rl.hpp): one persistent launch runs the K iterations of all
     // frames, a frame's spectrum staying in the L2 of the XCD whose team owns it.  f32, one view, in place,
@@ -402,6 +461,7 @@ struct rl_deconv {
 
     // noiseless = H(obj) on the device
     int forward_object() {
+        if (sep) return sep_forward(obj, noiseless, B);
         RL_TRY(row(ROW_FWD, (unsigned)B, nullptr, spec_a, obj, nullptr, nullptr));
         RL_TRY(col(spec_a, spec_b, B, true));
         RL_TRY(row(ROW_INV, (unsigned)(B * V), spec_b, nullptr, nullptr, noiseless, nullptr));
@@ -435,7 +495,7 @@ struct rl_deconv {
     // it when it takes H(1) from spec_ones (iterate_chunk(first = true)).
     int start_estimate_chunk(int f0, int nf, bool with_spectrum = true) {
         HIP_TRY(aux_fill(dtype, off(est, (size_t)f0 * n_img()), (size_t)nf * n_img(), 1.0, cur()));
-        if (with_spectrum)
+        if (with_spectrum && !sep)
             RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, off(spec_a, (size_t)f0 * n_spec() * 2), off(est, (size_t)f0 * n_img()),
                        nullptr, nullptr));
         return RL_OK;
@@ -458,6 +518,7 @@ struct rl_deconv {
             ~ScaleGuard() { q = keep; }
         } scale_guard{q_ratio, q_ratio};
         if (from_ones) q_ratio = q_est;
+        if (sep) return sep_iterate(f0, nf);
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         if (first && V == 1 && inplace) {
@@ -506,6 +567,12 @@ struct rl_deconv {
     }
     // noiseless = H(obj) on a slice
     int forward_slice(int f0, int nf) {
+        if (sep) {
+            const size_t o = (size_t)f0 * V * n_img();
+            if (sep_one) return sep2d_(SEP_STORE_, off(obj, (size_t)f0 * n_img()), nullptr, nullptr, off(noiseless, o), nf);
+            RL_TRY(sep_rows_(off(obj, (size_t)f0 * n_img()), off(sep_tmp(), o), nf * V, V));
+            return sep_cols_(SEP_STORE_, off(sep_tmp(), o), nullptr, nullptr, off(noiseless, o), nf * V);
+        }
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, sa, off(obj, (size_t)f0 * n_img()), nullptr, nullptr));
@@ -518,7 +585,7 @@ struct rl_deconv {
     // (optionally restart from est = 1 and) run k iterations, slice by slice
     int run_iterations(int k, bool restart) { return run_slices(k, restart, false, 0, 0); }
     int run_slices(int k, bool restart, bool simulate, int rng_kind, uint64_t seed) {
-        const bool use_fused = fused_available() && k > 0;
+        const bool use_fused = fused_available() && k > 0 && !sep;
         const int cf = chunk_frames();
         const int slices = (B + cf - 1) / cf;
         const int nl = slices < lanes ? slices : lanes;
@@ -587,7 +654,7 @@ struct rl_deconv {
             } else if (simulate) {
                 rc = simulate_slice(sl, f0, nf);
             }
-            const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !use_fused;
+            const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !use_fused && !sep;
             if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf, !shortcut);
             for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) rc = iterate_chunk(f0, nf, shortcut && i == 0, restart && i == 0);
         }
@@ -683,7 +750,7 @@ int rl_deconv_destroy(rl_deconv* h) {
         hipStreamDestroy(h->sim_stream);
     }
     for (hipEvent_t ev : h->sim_done) hipEventDestroy(ev);
-    void* bufs[] = {h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
+    void* bufs[] = {h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -808,6 +875,74 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         h->bytes += ones_bytes + RL_STREAM_SLACK;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // ---- strategy selection: direct separable stencils when every view is rank 1 and small ----
+    const int sep_mode = getenv("RLSTED_SEP") ? atoi(getenv("RLSTED_SEP")) : 1;
+    const int max_taps = getenv("RLSTED_SEP_MAX_TAPS") ? atoi(getenv("RLSTED_SEP_MAX_TAPS")) : 16;
+    if (sep_mode > 0 && (sep_mode > 1 || h->py + h->px <= max_taps) && h->py <= 4096 && h->px <= 4096) {
+        const size_t py = h->py, px = h->px;
+        std::vector<double> u(V * py), vv(V * px);
+        bool rank1 = true;
+        for (size_t v = 0; v < V && rank1; ++v) {
+            const double* p = psfs + v * py * px;
+            size_t a0 = 0, b0 = 0;
+            double pmax = 0.0;
+            for (size_t a = 0; a < py; ++a)
+                for (size_t b = 0; b < px; ++b)
+                    if (std::fabs(p[a * px + b]) > pmax) { pmax = std::fabs(p[a * px + b]); a0 = a; b0 = b; }
+            if (!(pmax > 0.0)) { rank1 = false; break; }
+            // cross approximation through the largest element: exact for a rank-1 matrix
+            for (size_t a = 0; a < py; ++a) u[v * py + a] = p[a * px + b0];
+            for (size_t b = 0; b < px; ++b) vv[v * px + b] = p[a0 * px + b] / p[a0 * px + b0];
+            for (size_t a = 0; a < py && rank1; ++a)
+                for (size_t b = 0; b < px; ++b)
+                    if (std::fabs(p[a * px + b] - u[v * py + a] * vv[v * px + b]) > 1e-12 * pmax) { rank1 = false; break; }
+        }
+        if (rank1) {
+            HIP_TRY(hipMalloc(&h->sep_u, V * py * es));
+            HIP_TRY(hipMalloc(&h->sep_v, V * px * es));
+            if (h->dtype == RL_F64) {
+                HIP_TRY(hipMemcpy(h->sep_u, u.data(), V * py * 8, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(h->sep_v, vv.data(), V * px * 8, hipMemcpyHostToDevice));
+            } else {
+                std::vector<float> uf(u.begin(), u.end()), vf(vv.begin(), vv.end());
+                HIP_TRY(hipMemcpy(h->sep_u, uf.data(), V * py * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(h->sep_v, vf.data(), V * px * 4, hipMemcpyHostToDevice));
+            }
+            h->sep = true;
+            // RLSTED_SEP_ONE: 0 two passes, 1 (default) one kernel up to 24 taps a side (beyond, the two-pass form is
+            // faster: profiles/r02/separable_vs_fft.json), 2 one kernel whenever the tile fits LDS
+            const int one_mode = getenv("RLSTED_SEP_ONE") ? atoi(getenv("RLSTED_SEP_ONE")) : 1;
+            const bool want_one = one_mode >= 2 || (one_mode == 1 && std::max(py, px) <= 24);
+            if (want_one && sep2d_fits(h->dtype, h->py, h->px, (int)V)) {
+                const size_t pyp = (py + 7) / 8 * 8, pxp = (px + 7) / 8 * 8;
+                std::vector<double> uf(V * pyp, 0.0), vf(V * pxp, 0.0);
+                for (size_t v = 0; v < V; ++v) {
+                    for (size_t k = 0; k < py; ++k) uf[v * pyp + k] = u[v * py + (py - 1 - k)];
+                    for (size_t k = 0; k < px; ++k) vf[v * pxp + k] = vv[v * px + (px - 1 - k)];
+                }
+                HIP_TRY(hipMalloc(&h->sep_uf, V * pyp * es));
+                HIP_TRY(hipMalloc(&h->sep_vf, V * pxp * es));
+                if (h->dtype == RL_F64) {
+                    HIP_TRY(hipMemcpy(h->sep_uf, uf.data(), V * pyp * 8, hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(h->sep_vf, vf.data(), V * pxp * 8, hipMemcpyHostToDevice));
+                } else {
+                    std::vector<float> a(uf.begin(), uf.end()), b(vf.begin(), vf.end());
+                    HIP_TRY(hipMemcpy(h->sep_uf, a.data(), V * pyp * 4, hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(h->sep_vf, b.data(), V * pxp * 4, hipMemcpyHostToDevice));
+                }
+                h->sep_one = true;
+            }
+            // H_t(ones) through the same stencils (ref:589-592); the V copies of ones live in scratch
+            HIP_TRY(aux_fill(h->dtype, h->scratch, V * h->n_img(), 1.0, ctx->stream));
+            if (h->sep_one) {
+                RL_TRY(h->sep2d_(SEP_SUM_, h->scratch, nullptr, nullptr, h->norm, 1));
+            } else {
+                RL_TRY(h->sep_rows_(h->scratch, h->sep_tmp(), (int)V, 1));
+                RL_TRY(h->sep_cols_(SEP_SUM_, h->sep_tmp(), nullptr, nullptr, h->norm, 1));
+            }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
     return RL_OK;
 }
 
@@ -943,7 +1078,7 @@ int rl_deconv_iterate(rl_deconv* h, int k) {
     HIP_TRY(hipSetDevice(h->ctx->device));
     HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
     bool restart = !h->est_ready;
-    if (!restart && !h->spec_valid) {   // H / H_t were called in between: rebuild rowFFT(est)
+    if (!restart && !h->spec_valid && !h->sep) {   // H / H_t were called in between: rebuild rowFFT(est)
         RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->est, nullptr, nullptr));
         h->spec_valid = true;
     }
@@ -976,6 +1111,10 @@ int rl_forward(rl_deconv* h, const double* x, double* out) {
     // overwrites spec_a / spec_b; the estimate itself is kept (spec_a is rebuilt by the next iterate)
     void* xin = h->scratch;   // first B images of scratch
     RL_TRY(h->upload(x, xin, (size_t)h->B * h->n_img()));
+    if (h->sep) {
+        RL_TRY(h->sep_forward(xin, h->scratch, h->B));   // the row pass has consumed xin before the column pass writes
+        return h->download(h->scratch, out, (size_t)h->B * h->V * h->n_img());
+    }
     RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, xin, nullptr, nullptr));
     RL_TRY(h->col(h->spec_a, h->spec_b, h->B, true));
     RL_TRY(h->row(ROW_INV, (unsigned)(h->B * h->V), h->spec_b, nullptr, nullptr, h->scratch, nullptr));
@@ -987,6 +1126,15 @@ int rl_adjoint(rl_deconv* h, const double* y, double* out, int normalize) {
     if (!h || !y || !out) return fail(RL_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(h->ctx->device));
     RL_TRY(h->upload(y, h->scratch, (size_t)h->B * h->V * h->n_img()));
+    if (h->sep && h->sep_one) {
+        RL_TRY(h->sep2d_(SEP_SUM_, h->scratch, nullptr, normalize ? h->norm : nullptr, h->spec_a, h->B));
+        return h->download(h->spec_a, out, (size_t)h->B * h->n_img());
+    }
+    if (h->sep) {
+        RL_TRY(h->sep_rows_(h->scratch, h->sep_tmp(), h->B * h->V, 1));
+        RL_TRY(h->sep_cols_(SEP_SUM_, h->sep_tmp(), nullptr, normalize ? h->norm : nullptr, h->spec_a, h->B));
+        return h->download(h->spec_a, out, (size_t)h->B * h->n_img());
+    }
     // row transform of every view image: run ROW_FWD with V folded into the frame index
     RL_TRY(h->row(ROW_FWD, (unsigned)(h->B * h->V), nullptr, h->spec_b, h->scratch, nullptr, nullptr));
     RL_TRY(h->col(h->spec_b, h->spec_b, h->B, false));
@@ -1024,6 +1172,14 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     return RL_OK;
 }
 
+
+int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl) {
+    if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (separable) *separable = h->sep ? 1 : 0;
+    if (real_psf_spectrum) *real_psf_spectrum = h->psf_hat_re ? 1 : 0;
+    if (fused_rl) *fused_rl = h->fused_available() ? 1 : 0;
+    return RL_OK;
+}
 
 int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx) {
     if (!h) return fail(RL_ERR_INVALID, "handle is NULL");

@@ -1,0 +1,124 @@
+"""The separable strategy (sep_kernels.hip): plans whose views are all rank 1 and small run H / H_t as row +
+column stencils.  Checked against the FFT strategy of the same library (RLSTED_SEP=0) and against the oracle;
+the strategy choice itself is checked through rl_deconv_strategy."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import max_rel
+from oracle import line_sted_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from rescan_line_sted_amd import _lib
+    assert _lib.device_count() >= 1, 'no GPU visible'
+    return _lib
+
+
+def plan_with(lib, sep, *args, one_kernel=True, **kw):
+    """A plan created under RLSTED_SEP=sep (0 FFT, 1 automatic, 2 separable whenever rank 1); one_kernel=False
+    keeps the two-pass form of the stencils (RLSTED_SEP_ONE=0), True asks for the one-kernel form whenever its tile fits LDS (=2)."""
+    knobs = {'RLSTED_SEP': str(sep), 'RLSTED_SEP_ONE': '2' if one_kernel else '0'}
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        return lib.DeconvPlan(*args, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def gauss(n, s, shift=0.0):
+    x = np.arange(n) - (n - 1) / 2 - shift
+    return np.exp(-x ** 2 / (2 * s ** 2))
+
+
+def rank1_views(kind):
+    if kind == 'row7':            # golden case G4's geometry: a 1 x 7 line
+        return [np.array([[1, 2, 3, 4, 3, 2, 1.0]])]
+    if kind == 'two_lines':       # 0 / 90 degree line PSFs: u v^T and its transpose
+        u, v = gauss(17, 1.2), gauss(17, 4.0)
+        return [np.outer(u, v), np.outer(v, u)]
+    if kind == 'even_skew':       # even sizes, asymmetric taps: the centre convention (py-1)//2 matters
+        return [np.outer(gauss(6, 1.5, 0.7), gauss(4, 1.0, -0.4)), np.outer(gauss(6, 0.8, -1.0), gauss(4, 2.0, 0.3))]
+    raise KeyError(kind)
+
+
+def planes(views):
+    return [np.asarray(v)[None] for v in views]          # the reference's (1, py, px) PSF stacks
+
+
+@pytest.mark.parametrize('one_kernel', [True, False])
+@pytest.mark.parametrize('kind,shape', [('row7', (33, 70)), ('two_lines', (128, 128)), ('even_skew', (61, 300))])
+def test_separable_matches_fft_strategy_and_oracle(lib, kind, shape, one_kernel):
+    views = planes(rank1_views(kind))
+    rng = np.random.default_rng(11)
+    B, (ny, nx) = 3, shape
+    obj = rng.random((B, ny, nx)) * 50
+    sep = plan_with(lib, 2, views, B, ny, nx, dtype='f64', one_kernel=one_kernel)
+    fft = plan_with(lib, 0, views, B, ny, nx, dtype='f64')
+    assert sep.strategy()['separable'] and not fft.strategy()['separable']
+    assert max_rel(sep.forward(obj), fft.forward(obj)) < 1e-12
+    y = rng.random((B, len(views), ny, nx))
+    for normalize in (True, False):
+        assert max_rel(sep.adjoint(y, normalize), fft.adjoint(y, normalize)) < 1e-12
+    for p in (sep, fft):
+        p.set_object(obj, 1e7)
+        p.simulate(seed=9)
+    assert max_rel(sep.noiseless(), fft.noiseless()) < 1e-12
+    assert np.array_equal(sep.measurement(), fft.measurement())      # ... and the same Poisson draws from it
+    for p in (sep, fft):
+        p.iterate(20)
+    assert max_rel(sep.estimate(), fft.estimate()) < 1e-11
+    for p in (sep, fft):                                             # continuing without a restart
+        p.iterate(5)
+    assert max_rel(sep.estimate(), fft.estimate()) < 1e-11
+    o = orc.Deconvolver(views)
+    o.create_data_from_object(obj[:1], noisy_measurement=[m[None] for m in sep.measurement()[0]])
+    for _ in range(25):
+        o.iterate()
+    assert max_rel(sep.estimate()[0], o.estimate[0]) < 1e-10
+
+
+def test_separable_f32_within_contract(lib):
+    views = planes(rank1_views('two_lines'))
+    rng = np.random.default_rng(12)
+    obj = rng.random((2, 128, 128)) * 50
+    p64 = plan_with(lib, 2, views, 2, 128, 128, dtype='f64')
+    p32 = plan_with(lib, 2, views, 2, 128, 128, dtype='f32')
+    assert p32.strategy()['separable']
+    p64.set_object(obj, 1e7)
+    p64.simulate(seed=2)
+    p32.set_object(obj, 1e7)
+    p32.set_measurement(p64.measurement())
+    for p in (p64, p32):
+        p.iterate(20)
+    assert max_rel(p32.estimate(), p64.estimate()) < 1e-5       # BASELINE f32 contract
+
+
+def test_strategy_choice(lib, golden):
+    big = golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][::2, 0]        # 107 x 107, the 0 / 90 degree views: rank 1 but large
+    assert not plan_with(lib, 1, planes(big), 1, 128, 128, dtype='f64').strategy()['separable']
+    ref = plan_with(lib, 0, planes(big), 1, 128, 128, dtype='f64')
+    x = np.random.default_rng(3).random((1, 128, 128))
+    y = np.random.default_rng(4).random((1, 2, 128, 128))
+    for one_kernel in (True, False):                                          # 107 taps: 120 KB of LDS in the one-kernel form
+        forced = plan_with(lib, 2, planes(big), 1, 128, 128, dtype='f64', one_kernel=one_kernel)
+        assert forced.strategy()['separable']
+        assert max_rel(forced.forward(x), ref.forward(x)) < 1e-12
+        assert max_rel(forced.adjoint(y), ref.adjoint(y)) < 1e-12
+    rot = golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][:, 0]
+    if len(rot) > 2:                                                          # a 45 degree view is not rank 1
+        assert not plan_with(lib, 2, planes(rot), 1, 128, 128).strategy()['separable']
+    small = planes([np.outer(gauss(7, 1.0), gauss(5, 2.0))])                 # automatic choice: rank 1 and py + px <= 16
+    assert plan_with(lib, 1, small, 1, 64, 64).strategy()['separable']
+    assert not plan_with(lib, 1, planes(rank1_views('two_lines')), 1, 64, 64).strategy()['separable']   # 17 + 17 taps: FFT is faster
+    blob = np.outer(gauss(9, 2), gauss(9, 2)) + np.eye(9) * 0.01             # small, full rank
+    assert not plan_with(lib, 2, planes([blob]), 1, 64, 64).strategy()['separable']
