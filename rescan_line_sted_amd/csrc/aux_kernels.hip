@@ -74,21 +74,24 @@ struct PoissonKeys {
 // noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510), in two launches so that
 // the rare slow path (log / log-gamma acceptance test, further attempts) does not run
 // with 13 % of the lanes active on every wave:
-//   k_poisson_fast  every pixel: first PTRS attempt; squeeze-accepted pixels are written,
-//                   the others are appended (index only) to a work list
-//   k_poisson_slow  the listed pixels, densely packed, through the full sampler
+//   k_poisson_fast  every pixel: first PTRS attempt; squeeze-accepted pixels are written, the others are
+//                   appended (index only) to the workgroup's segment of a work list: lam >= 10 from the
+//                   front, 0 < lam < 10 (multiplication method) from the back
+//   k_poisson_slow  the listed pixels, densely packed: the front range one PTRS attempt per round, the
+//                   survivors repacked in place between rounds (a wave never waits for its slowest lane's
+//                   fifth attempt); the back range through the multiplication loop
 // Values are a function of (seed, image, pixel) only, so the list order is irrelevant.
 // Each workgroup owns a fixed segment of the work list (capacity = the pixels it
-// visits), fills it through an LDS counter and publishes the fill level in counts[].
+// visits), fills it through LDS counters and publishes the fill levels in counts[2b], counts[2b+1].
 template <typename T>
-__global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
+__global__ void __launch_bounds__(256) k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
                                PoissonKeys keys, int rng_kind, unsigned* __restrict__ list,
                                unsigned seg_cap, unsigned* __restrict__ counts) {
-    __shared__ unsigned fill;
-    if (threadIdx.x == 0) fill = 0;
+    __shared__ unsigned fill, fill_small;
+    if (threadIdx.x == 0) fill = fill_small = 0;
     __syncthreads();
     unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
-    const size_t total = (size_t)n_pix * n_img;
+    const size_t total = (size_t)n_pix * n_img;                  // < 2^32 (aux_poisson)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 #if RL_POISSON_NT
         const double lam = (double)__builtin_nontemporal_load(&noiseless[i]);   // read once: keep it out of the caches
@@ -100,23 +103,56 @@ __global__ void k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ 
             continue;
         }
         double k;
-        const unsigned img = (unsigned)(i / n_pix);
-        if (philox_poisson_fast(lam, keys.seed(img), keys.image(img), (unsigned)(i % n_pix), &k)) noisy[i] = (T)(k + 1e-9);
-        else seg[atomicAdd(&fill, 1u)] = (unsigned)i;
+        const unsigned ii = (unsigned)i, img = ii / n_pix, pix = ii - img * n_pix;   // 32-bit division
+        if (philox_poisson_fast(lam, keys.seed(img), keys.image(img), pix, &k)) noisy[i] = (T)(k + 1e-9);
+        else if (lam >= 10.0) seg[atomicAdd(&fill, 1u)] = ii;
+        else seg[seg_cap - 1u - atomicAdd(&fill_small, 1u)] = ii;
     }
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = fill;
+    if (threadIdx.x == 0) {
+        counts[2 * blockIdx.x] = fill;
+        counts[2 * blockIdx.x + 1] = fill_small;
+    }
 }
 
 template <typename T>
-__global__ void k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, PoissonKeys keys, const unsigned* __restrict__ list, unsigned seg_cap,
-                               const unsigned* __restrict__ counts) {
-    const unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
-    const unsigned n = counts[blockIdx.x];
-    for (unsigned q = threadIdx.x; q < n; q += blockDim.x) {
-        const unsigned i = seg[q];
+__global__ void __launch_bounds__(256) k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, PoissonKeys keys,
+                               unsigned* __restrict__ list, unsigned seg_cap, const unsigned* __restrict__ counts) {
+    __shared__ unsigned fill;
+    unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
+    unsigned n = counts[2 * blockIdx.x];
+    const unsigned n_small = counts[2 * blockIdx.x + 1];
+    // lam >= 10: attempt `blk` of every pixel still listed (attempt 0 repeats the fast kernel's candidate and
+    // continues into the acceptance test it skipped)
+    for (unsigned blk = 0; n > 0; ++blk) {
+        if (threadIdx.x == 0) fill = 0;
+        __syncthreads();
+        const bool last = blk + 1 == kPoissonMaxBlocks;
+        for (unsigned base = 0; base < n; base += blockDim.x) {
+            const unsigned q = base + threadIdx.x;
+            bool again = false;
+            unsigned i = 0;
+            if (q < n) {
+                i = seg[q];
+                const unsigned img = i / n_pix, pix = i - img * n_pix;
+                const unsigned long long seed = keys.seed(img);
+                double k;
+                const bool done = philox_ptrs_attempt((double)noiseless[i], (unsigned)seed, (unsigned)(seed >> 32), keys.image(img), pix, blk, &k);
+                if (done || last) noisy[i] = (T)((done || k >= 0.0 ? k : 0.0) + 1e-9);
+                else again = true;
+            }
+            __syncthreads();                                     // this chunk has been read: positions < base + 256 may be rewritten
+            if (again) seg[atomicAdd(&fill, 1u)] = i;
+        }
+        __syncthreads();
+        n = fill;
+        __syncthreads();
+    }
+    // 0 < lam < 10: multiplication method, one pixel per lane
+    for (unsigned q = threadIdx.x; q < n_small; q += blockDim.x) {
+        const unsigned i = seg[seg_cap - 1u - q];
         const unsigned img = i / n_pix;
-        noisy[i] = (T)(philox_poisson((double)noiseless[i], keys.seed(img), keys.image(img), i % n_pix) + 1e-9);
+        noisy[i] = (T)(philox_poisson((double)noiseless[i], keys.seed(img), keys.image(img), i - img * n_pix) + 1e-9);
     }
 }
 
@@ -216,10 +252,10 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
     const size_t total = (size_t)n_pix * n_img;
     if (total >= 0xffffffffull) return hipErrorInvalidValue;      // 32-bit work-list entries
     const unsigned g = blocks_for(total, 256);
-    // list_ws layout: g segments of seg_cap entries (seg_cap * g <= total + g*256), then g counters
+    // list_ws layout: g segments of seg_cap entries (seg_cap * g <= total + g*256), then 2 g counters
     const unsigned seg_cap = (unsigned)((total + (size_t)g * 256 - 1) / ((size_t)g * 256)) * 256;
     unsigned* list = (unsigned*)list_ws;
-    unsigned* counts = list + (size_t)seg_cap * g;
+    unsigned* counts = list + (size_t)seg_cap * g;               // two per workgroup
     if (dtype == DT_F32) {
         k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, keys, rng_kind, list, seg_cap, counts);
         if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, keys, list, seg_cap, counts);
@@ -249,7 +285,7 @@ hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hip
 size_t aux_poisson_workspace_bytes(size_t total_pixels) {
     const unsigned g = blocks_for(total_pixels, 256);
     const size_t seg_cap = (total_pixels + (size_t)g * 256 - 1) / ((size_t)g * 256) * 256;
-    return (seg_cap * g + g) * sizeof(unsigned);
+    return (seg_cap * g + 2 * (size_t)g) * sizeof(unsigned);
 }
 
 }  // namespace rl

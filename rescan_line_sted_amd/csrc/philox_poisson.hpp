@@ -158,6 +158,34 @@ RL_HD bool philox_poisson_fast(double lam, uint64_t seed, uint32_t image, uint32
     return us >= 0.07 && V <= vr;
 }
 
+// One PTRS attempt (lam >= 10) with Philox block `blk`: returns true when the candidate *kout is accepted.
+// philox_poisson() below is a loop over this function; the device sampler calls it one attempt at a time so
+// that the pixels still undecided can be repacked densely between attempts.
+RL_HD bool philox_ptrs_attempt(double lam, uint32_t k0, uint32_t k1, uint32_t image, uint32_t pixel, uint32_t blk, double* kout) {
+    RL_FP_STRICT
+    const double slam = __builtin_sqrt(lam);
+    const double b = 0.931 + 2.53 * slam;
+    const double a = -0.059 + 0.02483 * b;
+    const double vr = 0.9277 - 3.6224 / (b - 2.0);
+    const Philox4 o = philox4x32_10(pixel, image, blk, 0x504F4953u, k0, k1);
+    const double U = u53(o.x[0], o.x[1]) - 0.5;
+    const double V = u53(o.x[2], o.x[3]);
+    const double us = 0.5 - (U < 0.0 ? -U : U);
+    const double k = __builtin_floor((2.0 * a / us + b) * U + lam + 0.43);
+    *kout = k;
+    if (us >= 0.07 && V <= vr) return true;                      // ~87 % of attempts leave here
+    if (k < 0.0 || (us < 0.013 && V > us)) return false;
+    if (!(V > 0.0)) return true;
+    // slow path: the logarithms are evaluated only here (same values as if hoisted)
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double loglam = det_log(lam);
+    const double lhs = (det_log(V) + det_log(invalpha)) - det_log(a / (us * us) + b);
+    const double rhs = (k * loglam - lam) - det_logfact(k);
+    return lhs <= rhs;
+}
+
+constexpr uint32_t kPoissonMaxBlocks = 64;   // attempts per pixel, then the last candidate is taken
+
 // One Poisson variate for (seed, image, pixel).
 RL_HD double philox_poisson(double lam, uint64_t seed, uint32_t image, uint32_t pixel) {
     RL_FP_STRICT
@@ -166,7 +194,7 @@ RL_HD double philox_poisson(double lam, uint64_t seed, uint32_t image, uint32_t 
     if (lam < 10.0) {
         const double enlam = det_exp(-lam);
         double X = 0.0, prod = 1.0;
-        for (uint32_t blk = 0; blk < 64; ++blk) {
+        for (uint32_t blk = 0; blk < kPoissonMaxBlocks; ++blk) {
             const Philox4 o = philox4x32_10(pixel, image, blk, 0x504F4953u, k0, k1);
             prod = prod * u53(o.x[0], o.x[1]);
             if (!(prod > enlam)) return X;
@@ -177,27 +205,9 @@ RL_HD double philox_poisson(double lam, uint64_t seed, uint32_t image, uint32_t 
         }
         return X;
     }
-    const double slam = __builtin_sqrt(lam);
-    const double b = 0.931 + 2.53 * slam;
-    const double a = -0.059 + 0.02483 * b;
-    const double vr = 0.9277 - 3.6224 / (b - 2.0);
-    double k = __builtin_floor(lam);
-    for (uint32_t blk = 0; blk < 64; ++blk) {
-        const Philox4 o = philox4x32_10(pixel, image, blk, 0x504F4953u, k0, k1);
-        const double U = u53(o.x[0], o.x[1]) - 0.5;
-        const double V = u53(o.x[2], o.x[3]);
-        const double us = 0.5 - (U < 0.0 ? -U : U);
-        k = __builtin_floor((2.0 * a / us + b) * U + lam + 0.43);
-        if (us >= 0.07 && V <= vr) return k;                     // ~87 % of pixels leave here
-        if (k < 0.0 || (us < 0.013 && V > us)) continue;
-        if (!(V > 0.0)) return k;
-        // slow path: the logarithms are evaluated only here (same values as if hoisted)
-        const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-        const double loglam = det_log(lam);
-        const double lhs = (det_log(V) + det_log(invalpha)) - det_log(a / (us * us) + b);
-        const double rhs = (k * loglam - lam) - det_logfact(k);
-        if (lhs <= rhs) return k;
-    }
+    double k = 0.0;
+    for (uint32_t blk = 0; blk < kPoissonMaxBlocks; ++blk)
+        if (philox_ptrs_attempt(lam, k0, k1, image, pixel, blk, &k)) return k;
     return k < 0.0 ? 0.0 : k;
 }
 

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench
 from rescan_line_sted_amd import _lib
-obj, psf, brightness = bench.workload()
+obj, psf, brightness, _ = bench.workload(512)
 if len(sys.argv) > 3:      # e.g. 2p0x_lr/line_sted_psfs
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
     psf = [p[None] for p in g[sys.argv[3]][:, 0]]
