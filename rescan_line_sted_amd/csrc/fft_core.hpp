@@ -50,18 +50,89 @@ RL_HD cx<T> scale(cx<T> a, T s) { return mk<T>(a.re * s, a.im * s); }
 template <bool INV, typename T>
 RL_HD cx<T> rot90(cx<T> a) { return INV ? mk<T>(-a.im, a.re) : mk<T>(a.im, -a.re); }
 
+// ---- packed single precision (gfx950: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on a register pair) ----
+// cx<float> keeps (re, im) in one 2-vector so that a complex add is ONE instruction and a complex multiply two:
+// the swaps and sign flips of complex arithmetic ride on the instructions' op_sel / neg modifiers.  LLVM's SLP
+// vectoriser finds the same pairs from scalar code only at the price of ~200 v_mov shuffles per transform
+// (_build.py keeps it off); written on vectors there is nothing to re-pair.  Members .re / .im stay accessible
+// (anonymous struct in a union) for the pointwise stages.
+// MEASURED (round 2): 24 % fewer VALU instructions per wave (column kernel 953 -> 728, ROW_RATIO 958 -> 738, ROW_UPDATE
+// 994 -> 767) and NO gain: headline 17.5 k frames/s either way, column kernel alone 26.8 -> 29.2 us per 32-frame launch
+// (L = 2304: 341 -> 372 us) -- the kernels move bytes at the memory system's mixed read/write rate and the VALU was never the
+// critical resource.  Rounding differs slightly (other FMA pairings: 7.9e-6 instead of 6.2e-6 against
+// the float64 oracle at K = 20).  Hence OFF by default; `python -m rescan_line_sted_amd._build --variant pk` builds it.
+#ifndef RL_PACKED_F32
+#define RL_PACKED_F32 0
+#endif
+#if defined(__HIPCC__) && RL_PACKED_F32
+typedef float rl_v2f __attribute__((ext_vector_type(2)));
+template <>
+struct cx<float> {
+    union {
+        rl_v2f v;
+        struct {
+            float re, im;
+        };
+    };
+};
+RL_HD cx<float> mkv(rl_v2f v) {
+    cx<float> r;
+    r.v = v;
+    return r;
+}
+RL_HD cx<float> operator+(cx<float> a, cx<float> b) { return mkv(a.v + b.v); }
+RL_HD cx<float> operator-(cx<float> a, cx<float> b) { return mkv(a.v - b.v); }
+RL_HD cx<float> scale(cx<float> a, float s) { return mkv(a.v * s); }
+RL_HD cx<float> cmul(cx<float> a, cx<float> b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const rl_v2f t = a.v.xx * b.v;   // (a.re b.re, a.re b.im)
+    rl_v2f r;                        // (a.im * -b.im + t.x, a.im * b.re + t.y): one lane negated is beyond the compiler's patterns
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a.v), "v"(b.v), "v"(t));
+    return mkv(r);
+#else
+    return mk<float>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+#endif
+}
+template <bool INV>
+RL_HD cx<float> rot90(cx<float> a) {
+    return mkv(INV ? rl_v2f{-a.v.y, a.v.x} : rl_v2f{a.v.y, -a.v.x});
+}
+// a +- rot90<INV>(b) in one instruction: the swap is op_sel, the single negated lane neg_lo / neg_hi
+template <bool INV>
+RL_HD cx<float> add_rot(cx<float> a, cx<float> b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    rl_v2f r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));   // (a.re - b.im, a.im + b.re)
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));       // (a.re + b.im, a.im - b.re)
+    return mkv(r);
+#else
+    return INV ? mk<float>(a.re - b.im, a.im + b.re) : mk<float>(a.re + b.im, a.im - b.re);
+#endif
+}
+template <bool INV>
+RL_HD cx<float> sub_rot(cx<float> a, cx<float> b) { return add_rot<!INV>(a, b); }
+// a * (c + i s) for constants: both tap vectors are literals, no run-time sign flip
+RL_HD cx<float> cmul_const(cx<float> a, float c, float s) { return mkv(a.v.xx * rl_v2f{c, s} + a.v.yy * rl_v2f{-s, c}); }
+#endif
+template <typename T>
+RL_HD cx<T> cmul_const(cx<T> a, T c, T s) { return mk<T>(a.re * c - a.im * s, a.re * s + a.im * c); }
+template <bool INV, typename T>
+RL_HD cx<T> add_rot(cx<T> a, cx<T> b) { return a + rot90<INV>(b); }
+template <bool INV, typename T>
+RL_HD cx<T> sub_rot(cx<T> a, cx<T> b) { return a - rot90<INV>(b); }
+
 // v *= exp(-+ 2 pi i m / R) for compile-time-foldable (R, m)
 template <bool INV, typename T>
 RL_HD cx<T> twiddle_const(cx<T> a, int R, int m) {
     m %= R;
     if (m == 0) return a;
     if (4 * m == R) return rot90<INV>(a);
-    if (2 * m == R) return mk<T>(-a.re, -a.im);
+    if (2 * m == R) return scale(a, (T)-1);
     if (4 * m == 3 * R) return rot90<!INV>(a);
     const double ang = 6.283185307179586476925286766559 * (double)m / (double)R;
     const T c = (T)__builtin_cos(ang);
     const T s = (T)(INV ? __builtin_sin(ang) : -__builtin_sin(ang));
-    return mk<T>(a.re * c - a.im * s, a.re * s + a.im * c);
+    return cmul_const(a, c, s);
 }
 
 template <int R>
@@ -80,31 +151,31 @@ RL_HD void dft(cx<T>* v) {
         v[1] = b;
     } else if constexpr (R == 3) {
         cx<T> t = v[1] + v[2];
-        cx<T> m = mk<T>(v[0].re - (T)0.5 * t.re, v[0].im - (T)0.5 * t.im);
-        cx<T> d = rot90<INV>(scale(v[1] - v[2], (T)0.86602540378443864676372317075294));
+        cx<T> m = v[0] - scale(t, (T)0.5);
+        cx<T> d = scale(v[1] - v[2], (T)0.86602540378443864676372317075294);
         v[0] = v[0] + t;
-        v[1] = m + d;
-        v[2] = m - d;
+        v[1] = add_rot<INV>(m, d);
+        v[2] = sub_rot<INV>(m, d);
     } else if constexpr (R == 4) {
         cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3];
-        cx<T> t3 = rot90<INV>(v[1] - v[3]);
+        cx<T> t3 = v[1] - v[3];
         v[0] = t0 + t2;
-        v[1] = t1 + t3;
+        v[1] = add_rot<INV>(t1, t3);
         v[2] = t0 - t2;
-        v[3] = t1 - t3;
+        v[3] = sub_rot<INV>(t1, t3);
     } else if constexpr (R == 5) {
         const T c1 = (T)0.30901699437494742410229341718282, c2 = (T)-0.80901699437494742410229341718282;
         const T s1 = (T)0.95105651629515357211643933337938, s2 = (T)0.58778525229247312916870595463907;
         cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
-        cx<T> m1 = mk<T>(v[0].re + c1 * a1.re + c2 * a2.re, v[0].im + c1 * a1.im + c2 * a2.im);
-        cx<T> m2 = mk<T>(v[0].re + c2 * a1.re + c1 * a2.re, v[0].im + c2 * a1.im + c1 * a2.im);
-        cx<T> n1 = rot90<INV>(mk<T>(s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im));
-        cx<T> n2 = rot90<INV>(mk<T>(s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im));
+        cx<T> m1 = v[0] + scale(a1, c1) + scale(a2, c2);
+        cx<T> m2 = v[0] + scale(a1, c2) + scale(a2, c1);
+        cx<T> n1 = scale(b1, s1) + scale(b2, s2);
+        cx<T> n2 = scale(b1, s2) - scale(b2, s1);
         v[0] = v[0] + a1 + a2;
-        v[1] = m1 + n1;
-        v[4] = m1 - n1;
-        v[2] = m2 + n2;
-        v[3] = m2 - n2;
+        v[1] = add_rot<INV>(m1, n1);
+        v[4] = sub_rot<INV>(m1, n1);
+        v[2] = add_rot<INV>(m2, n2);
+        v[3] = sub_rot<INV>(m2, n2);
     } else {
         // Cooley-Tukey R = R1*R2: n = R2*n1 + n2, k = k1 + R1*k2
         constexpr int R1 = radix_split<R>::R1, R2 = radix_split<R>::R2;
