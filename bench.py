@@ -18,7 +18,8 @@ over ranks counts, and ONE gather of the final estimates over RCCL / xGMI follow
 The barrier, the reduction and the gather are the C ABI's (rl_comm_*, rl_gather*: RCCL loaded by
 librlsted.so itself); torch.distributed is only the fallback transport should that fail to start.
 
---size 2048 is BASELINE config 3 (synthetic 2048x2048 object, line-rescan, 4 views).
+--size 2048 is BASELINE config 3 (synthetic 2048x2048 object, line-rescan, 4 views); the default single-GPU run
+also carries three steps of it as "size_2048" in the same JSON line (--no-2048 skips them).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -250,6 +251,33 @@ def accuracy(plan, psf, size, dtype):
             'contract': 1e-5 if dtype == 'f32' else 1e-10}
 
 
+def second_size(size, B, steps, warmup, device):
+    """`steps` whole cycles (simulate + 20 RL iterations) of `B` frames of the --size 2048 workload, timed like
+    the headline (synchronise, wall clock, synchronise)."""
+    from rescan_line_sted_amd import _lib
+    obj, psf, brightness, name = workload(size)
+    plan = _lib.DeconvPlan(psf, B, size, size, dtype='f32', device=device)
+    plan.set_object(np.broadcast_to(obj, (B, size, size)), brightness)
+    for w in range(warmup):
+        plan.bench_cycles(K_ITERS, 1, seed=w)
+    plan.ctx.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        plan.bench_cycles(K_ITERS, 1, seed=warmup + s)
+    plan.ctx.synchronize()
+    el = time.perf_counter() - t0
+    est = plan.estimate()
+    assert np.isfinite(est).all() and est.min() >= 0
+    value = B * steps / el
+    alg = algorithmic_bytes_per_frame(size * size, len(psf), K_ITERS)
+    info = plan.info()
+    return {'metric': 'simulated frames/s (%dx%d, 20 RL iters)' % (size, size), 'value': value, 'unit': 'frames/s',
+            'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3, 'dtype': 'f32',
+            'config': {'workload': name, 'frames_per_gpu_per_step': B, 'n_psf': len(psf), 'rl_iters': K_ITERS,
+                       'fft': '%dx%d' % (info['ly'], info['lx'])},
+            'whole_path': {'algorithmic_bytes_per_frame': alg, 'GBps': alg * value / 1e9, 'frac': alg * value / 1e9 / HBM_PEAK_GBS}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -260,6 +288,7 @@ def main():
     ap.add_argument('--size', type=int, default=512, choices=(512, 2048))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true')
+    ap.add_argument('--no-2048', action='store_true', help='skip the short 2048 x 2048 leg of the default run')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -413,6 +442,14 @@ def main():
         out['accuracy'] = accuracy(plan, psf, size, args.dtype)
     if cpu is not None:
         out['cpu_baseline'] = cpu
+    # the north star's second reporting size in the same record: a few steps of BASELINE config 3's shape
+    # (2048 x 2048, line-rescan, 4 views); single-process runs only -- the N-rank runs measure the headline
+    if size == 512 and world == 1 and comm is None and not stub and not args.no_2048 and args.dtype == 'f32':
+        try:
+            del plan
+            out['size_2048'] = second_size(2048, 32, 3, 1, local_rank)
+        except Exception as exc:     # reported, never allowed to void the headline
+            out['size_2048'] = {'error': repr(exc)}
     if comm is not None:
         assert out['n_gpus'] == args.gpus
         if gather and rank == 0 and 'frames_on_root' in gather:
