@@ -47,6 +47,13 @@ const char* rl_last_error(void);
 int rl_version(void);
 int rl_device_count(int* count);
 
+/* Page-locked host memory for the buffers handed to the calls below: the float64 arrays of the reference's
+ * call surface (line_sted_tools.py:496-531: obj, noisy_measurement, estimate are host numpy arrays) then cross
+ * PCIe by direct DMA instead of through the runtime's pageable-copy staging.
+ * Purely optional: every entry point accepts ordinary host pointers.                                        */
+int rl_host_alloc(size_t bytes, void** out);
+int rl_host_free(void* p);
+
 /* One context per GPU: owns the stream and the per-length twiddle tables. */
 int rl_ctx_create(int device, rl_ctx** out);
 int rl_ctx_destroy(rl_ctx* ctx);

@@ -48,6 +48,8 @@ PROTOTYPES = {
     'rl_deconv_time_kernels': (_i, [_vp, _i, _dp]),
     'rl_deconv_time_cycle': (_i, [_vp, _i, _i, _c.c_uint64, _dp, _dp, _dp]),
     'rl_deconv_device_ptr': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
+    'rl_host_alloc': (_i, [_c.c_size_t, _c.POINTER(_vp)]),
+    'rl_host_free': (_i, [_vp]),
     'rl_deconv_strategy': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_deconv_dims': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_batch_run': (_i, [_vp, _vp, _i, _i, _i, _dp]),
@@ -103,6 +105,30 @@ def as_f64(a):
 
 def ptr(a):
     return a.ctypes.data_as(_dp)
+
+
+class _Pinned:
+    """One rl_host_alloc block, exposed to numpy through __array_interface__ (numpy keeps this object as the
+    base of every view, so the block is freed when the last view dies)."""
+
+    def __init__(self, nbytes):
+        self.p = _vp()
+        check(lib.rl_host_alloc(nbytes, ctypes.byref(self.p)))
+        self.__array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (self.p.value, False), 'version': 3}
+
+    def __del__(self):
+        if getattr(self, 'p', None) and lib is not None:
+            lib.rl_host_free(self.p)
+            self.p = None
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (rl_host_alloc): pass it as the object / measurement, or as
+    `out=` of the getters, and it crosses PCIe by direct DMA."""
+    shape = tuple(int(x) for x in np.atleast_1d(shape))
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    return np.asarray(_Pinned(max(n, dt.itemsize)))[:n].view(dt).reshape(shape)
 
 
 def device_count():
@@ -189,22 +215,26 @@ class DeconvPlan:
         est = as_f64(est).reshape(self.B, self.ny, self.nx)
         check(lib.rl_deconv_set_estimate(self.handle, ptr(est)))
 
-    def _get(self, fn, shape):
-        out = np.empty(shape, dtype=np.float64)
+    def _get(self, fn, shape, out=None):
+        if out is None:
+            out = np.empty(shape, dtype=np.float64)
+        elif out.dtype != np.float64 or not out.flags.c_contiguous or out.size != int(np.prod(shape)):
+            raise ValueError('out must be a C-contiguous float64 array of %d elements' % int(np.prod(shape)))
         check(fn(self.handle, ptr(out)))
-        return out
+        return out if out.shape == tuple(shape) else out.reshape(shape)
 
-    def object(self):
-        return self._get(lib.rl_deconv_get_object, (self.B, self.ny, self.nx))
+    def object(self, out=None):
+        return self._get(lib.rl_deconv_get_object, (self.B, self.ny, self.nx), out)
 
-    def noiseless(self):
-        return self._get(lib.rl_deconv_get_noiseless, (self.B, self.V, self.ny, self.nx))
+    def noiseless(self, out=None):
+        return self._get(lib.rl_deconv_get_noiseless, (self.B, self.V, self.ny, self.nx), out)
 
-    def measurement(self):
-        return self._get(lib.rl_deconv_get_measurement, (self.B, self.V, self.ny, self.nx))
+    def measurement(self, out=None):
+        return self._get(lib.rl_deconv_get_measurement, (self.B, self.V, self.ny, self.nx), out)
 
-    def estimate(self):
-        return self._get(lib.rl_deconv_get_estimate, (self.B, self.ny, self.nx))
+    def estimate(self, out=None):
+        """out: a float64 array to fill (e.g. pinned_empty(...)) instead of a fresh allocation."""
+        return self._get(lib.rl_deconv_get_estimate, (self.B, self.ny, self.nx), out)
 
     def normalization(self):
         return self._get(lib.rl_deconv_get_normalization, (self.ny, self.nx))

@@ -698,6 +698,19 @@ int rl_device_count(int* count) {
     return RL_OK;
 }
 
+int rl_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(RL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return fail(RL_ERR_INVALID, "bytes == 0");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return RL_OK;
+}
+
+int rl_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return RL_OK;
+}
+
 int rl_fft_length_for(int n) {
     for (int L : kLengths)
         if (L >= n) return L;

@@ -102,7 +102,7 @@ class Deconvolver:
         assert len(obj.shape) == 3                      # ref:502
         assert obj.dtype == np.float64                  # ref:503
         if self._estimate_stale and self._plan is not None:   # fetch before the plan's measurement changes
-            self._estimate, self._estimate_stale = self._plan.estimate(), False
+            self._fetch_estimate()
         plan = self._plan_for(obj.shape)
         plan.set_object(obj, None if total_brightness is None
                         else self._brightness(obj, total_brightness))
@@ -176,9 +176,10 @@ class Deconvolver:
         if not getattr(self, '_measurement_on_device', False):
             self._push_measurement()
         plan = self._plan
-        if self.num_iterations == 0:                      # ref:521-522: always from ones
+        if self.num_iterations == 0:                      # ref:521-522: always from ones (a NEW array there)
             plan.reset_estimate()
             self._estimate_push = False
+            self._estimate = None
         self._sync_estimate(plan)
         self.num_iterations += 1
         plan.iterate(1)
@@ -192,16 +193,27 @@ class Deconvolver:
         if self.num_iterations == 0:
             self._plan.reset_estimate()
             self._estimate_push = False
+            self._estimate = None
         self._sync_estimate(self._plan)
         self.num_iterations += k
         self._plan.iterate(k)
         self._estimate_stale = True
 
+    def _fetch_estimate(self):
+        """The reference updates ONE array in place (`self.estimate *= ...`, ref:531); so does the mirror: the
+        host copy is refreshed into the array handed out before (a fresh 2 MB-per-frame array costs more in
+        page faults than its PCIe transfer)."""
+        plan, buf = self._plan, self._estimate
+        if not (isinstance(buf, np.ndarray) and buf.dtype == np.float64 and buf.flags.c_contiguous
+                and buf.flags.writeable and buf.shape == (plan.B, plan.ny, plan.nx)):
+            buf = None
+        self._estimate = plan.estimate(out=buf)
+        self._estimate_stale = False
+
     @property
     def estimate(self):
         if self._estimate_stale:
-            self._estimate = self._plan.estimate()
-            self._estimate_stale = False
+            self._fetch_estimate()
         if self._estimate is None:
             raise AttributeError('estimate')          # like the reference before iterate()
         return self._estimate

@@ -88,3 +88,34 @@ def test_multi_view_record_and_load_round_trip(st, views, obj, tmp_path):
     for _ in range(3):
         e.iterate()
     assert max_rel(e.estimate, d.estimate) < 1e-6      # the TIF stores float32
+
+
+def test_estimate_is_one_array_updated_in_place(st, views, obj, tmp_path):
+    """ref:531 `self.estimate *= ...`: whoever holds d.estimate sees the next iteration in it."""
+    d = st.Deconvolver(views, str(tmp_path) + '/', verbose=False)
+    d.create_data_from_object(obj, 5e10, random_seed=3)
+    d.iterate()
+    held = d.estimate
+    first = held.copy()
+    d.iterate()
+    assert d.estimate is held and not np.array_equal(held, first)
+    d.num_iterations = 0                 # the reference starts over with a NEW array of ones (ref:521-522)
+    d.iterate()
+    assert d.estimate is not held and max_rel(d.estimate, first) < 1e-12
+
+
+def test_pinned_host_arrays_and_out_argument(st, views, obj):
+    from rescan_line_sted_amd import _lib
+    plan = _lib.DeconvPlan(views, obj.shape[0], obj.shape[1], obj.shape[2], dtype='f64')
+    frames = _lib.pinned_empty(obj.shape)
+    frames[:] = obj
+    plan.set_object(frames, 5e10)
+    plan.simulate(seed=1)
+    plan.iterate(3)
+    out = _lib.pinned_empty(obj.shape)
+    got = plan.estimate(out=out)
+    assert got is out
+    assert np.array_equal(got, plan.estimate())
+    with pytest.raises(ValueError):
+        plan.estimate(out=np.empty(3))
+    del frames, out, got                 # the blocks are released with their last views
