@@ -108,6 +108,7 @@ struct rl_deconv {
     hipStream_t sim_stream = nullptr;                 // run_cycle(): simulation of all slices, ahead of the RL lanes
     std::vector<hipEvent_t> sim_done;                 // one per slice
     bool sim_ahead = false;                           // RLSTED_SIM_AHEAD=1 (measured -4 %: see run_slices)
+    bool defer_join = false, lanes_open = false;      // rl_deconv_bench_cycles: no lane join between its cycles
     void* slice_ws = nullptr;                         // per-slice Poisson work lists of run_cycle()
     void *key_seeds = nullptr, *key_ids = nullptr;    // per-frame Philox keys of rl_deconv_simulate_keyed
     size_t slice_ws_bytes = 0, slice_ws_stride = 0;
@@ -582,6 +583,16 @@ struct rl_deconv {
     }
     // one whole simulate + deconvolve cycle, slice by slice
     int run_cycle(int k, int rng_kind, uint64_t seed) { return run_slices(k, true, true, rng_kind, seed); }
+    int join_open_lanes() {   // after a failed cycle between deferred joins
+        if (!lanes_open) return RL_OK;
+        lanes_open = false;
+        for (int l = 0; l < kMaxLanes; ++l) {
+            if (!lane_stream[l]) continue;
+            HIP_TRY(hipEventRecord(lane_done[l], lane_stream[l]));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, lane_done[l], 0));
+        }
+        return RL_OK;
+    }
     // (optionally restart from est = 1 and) run k iterations, slice by slice
     int run_iterations(int k, bool restart) { return run_slices(k, restart, false, 0, 0); }
     int run_slices(int k, bool restart, bool simulate, int rng_kind, uint64_t seed) {
@@ -594,7 +605,10 @@ struct rl_deconv {
             iterations += k;
             return RL_OK;
         }
-        if (nl > 1) {
+        // Lanes stay open between the back-to-back cycles of rl_deconv_bench_cycles (defer_join): slice s of every cycle
+        // goes to the same lane, so stream order alone keeps each slice's buffers consistent and the lanes need not meet.
+        const bool keep_open = defer_join && nl > 1 && !use_fused && !sim_ahead;
+        if (nl > 1 && !lanes_open) {
             RL_TRY(ensure_lanes());
             HIP_TRY(hipEventRecord(fork, ctx->stream));
             for (int l = 0; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(lane_stream[l], fork, 0));
@@ -663,11 +677,14 @@ struct rl_deconv {
             HIP_TRY(hipEventRecord(fork, sim_stream));
             HIP_TRY(hipStreamWaitEvent(ctx->stream, fork, 0));
         }
-        if (nl > 1) {   // join, also on errors: the context's stream continues after every lane
+        if (nl > 1 && (!keep_open || rc != RL_OK)) {   // join, also on errors: the context's stream continues after every lane
             for (int l = 0; l < nl; ++l) {
                 HIP_TRY(hipEventRecord(lane_done[l], lane_stream[l]));
                 HIP_TRY(hipStreamWaitEvent(ctx->stream, lane_done[l], 0));
             }
+            lanes_open = false;
+        } else if (nl > 1) {
+            lanes_open = true;
         }
         RL_TRY(rc);
         if (use_fused) RL_TRY(fused_launch(0, B, k));   // all iterations of all frames, after the lanes have joined
@@ -1173,7 +1190,15 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     for (int r = 0; r < reps; ++r) {
         // per slice of the batch: noiseless = H(obj), noisy = Poisson(noiseless) + 1e-9, est = 1,
         // k iterations -- the same values as rl_deconv_simulate + rl_deconv_iterate over the batch
-        RL_TRY(h->run_cycle(k, rng_kind, seed + (uint64_t)r));
+        h->defer_join = r + 1 < reps;
+        const int rc = h->run_cycle(k, rng_kind, seed + (uint64_t)r);
+        h->defer_join = false;
+        if (rc != RL_OK) {
+            const std::string keep = rl::last_error();
+            h->join_open_lanes();
+            rl::last_error() = keep;
+            return rc;
+        }
         h->have_meas = true;
     }
     HIP_TRY(hipEventRecord(h->ev1, s));

@@ -276,7 +276,7 @@ def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lan
     objs = np.concatenate([astronaut512, rng.random((B - 1, 512, 512)) * 200])
     a = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
     a.set_object(objs, 8e11)
-    a.bench_cycles(K, 2, seed=40)                      # two cycles: seeds 40, 41; the last one stays
+    a.bench_cycles(K, 3, seed=39)                      # three cycles back to back (no lane join in between): seeds 39, 40, 41; the last one stays
     b = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
     b.set_object(objs, 8e11)
     b.simulate(seed=41)
