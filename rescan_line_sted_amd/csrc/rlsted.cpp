@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "aux_kernels.hpp"
@@ -1186,6 +1187,7 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     if (k < 0 || reps < 1) return fail(RL_ERR_INVALID, "bad k / reps");
     HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
+    const auto t_start = std::chrono::steady_clock::now();
     HIP_TRY(hipEventRecord(h->ev0, s));
     for (int r = 0; r < reps; ++r) {
         // per slice of the batch: noiseless = H(obj), noisy = Poisson(noiseless) + 1e-9, est = 1,
@@ -1202,10 +1204,14 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
         h->have_meas = true;
     }
     HIP_TRY(hipEventRecord(h->ev1, s));
+    const auto t_enq = std::chrono::steady_clock::now();
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *total_ms = ms;
+    if (getenv("RLSTED_DEBUG_ENQUEUE"))   // how far the host runs ahead of the device: enqueue time against device time
+        fprintf(stderr, "rl_deconv_bench_cycles: host enqueue %.3f ms, device %.3f ms\n",
+                std::chrono::duration<double, std::milli>(t_enq - t_start).count(), (double)ms);
     RL_TRY(h->fused_check());
     return RL_OK;
 }
