@@ -1143,8 +1143,11 @@ int rl_forward(rl_deconv* h, const double* x, double* out) {
     void* xin = h->scratch;   // first B images of scratch
     RL_TRY(h->upload(x, xin, (size_t)h->B * h->n_img()));
     if (h->sep) {
-        RL_TRY(h->sep_forward(xin, h->scratch, h->B));   // the row pass has consumed xin before the column pass writes
-        return h->download(h->scratch, out, (size_t)h->B * h->V * h->n_img());
+        // xin lives in scratch.  Two passes: the row pass has consumed xin before the column pass writes scratch.
+        // One kernel: its workgroups read halos of xin while others store -- the result goes to the (idle) spectrum buffer.
+        void* res = h->sep_one ? h->sep_tmp() : h->scratch;
+        RL_TRY(h->sep_forward(xin, res, h->B));
+        return h->download(res, out, (size_t)h->B * h->V * h->n_img());
     }
     RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, xin, nullptr, nullptr));
     RL_TRY(h->col(h->spec_a, h->spec_b, h->B, true));

@@ -122,3 +122,36 @@ def test_strategy_choice(lib, golden):
     assert not plan_with(lib, 1, planes(rank1_views('two_lines')), 1, 64, 64).strategy()['separable']   # 17 + 17 taps: FFT is faster
     blob = np.outer(gauss(9, 2), gauss(9, 2)) + np.eye(9) * 0.01             # small, full rank
     assert not plan_with(lib, 2, planes([blob]), 1, 64, 64).strategy()['separable']
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_separable_random_small_cases_vs_oracle(lib, seed):
+    """Automatic choice (py + px <= 16) on ragged shapes: images smaller than a tile, smaller than the PSF,
+    1-pixel rows / columns, several views and frames -- H, H_t and three iterations against the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    ny, nx = int(rng.integers(1, 71)), int(rng.integers(1, 140))
+    py, px = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    V, B = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    views = planes([np.outer(rng.random(py) + 0.1, rng.random(px) + 0.1) for _ in range(V)])
+    plan = lib.DeconvPlan(views, B, ny, nx, dtype='f64')
+    assert plan.strategy()['separable']
+    x = rng.random((B, ny, nx)) * 30
+    o = orc.Deconvolver(views)
+    h = plan.forward(x)
+    for f in range(B):
+        ref = o.H(x[f][None])
+        errs = [max_rel(h[f, v], ref[v][0]) for v in range(V)]
+        assert max(errs) < 1e-12, (ny, nx, py, px, V, B, errs)
+    y = rng.random((B, V, ny, nx)) + 0.5
+    ht = plan.adjoint(y, True)
+    for f in range(B):
+        assert max_rel(ht[f], o.H_t([y[f, v][None] for v in range(V)])[0]) < 1e-12
+    plan.set_object(x)
+    plan.set_measurement(y)
+    plan.iterate(3)
+    for f in range(B):
+        d = orc.Deconvolver(views)
+        d.create_data_from_object(x[f][None], noisy_measurement=[y[f, v][None] for v in range(V)])
+        for _ in range(3):
+            d.iterate()
+        assert max_rel(plan.estimate()[f], d.estimate[0]) < 1e-11, (ny, nx, py, px, V, B)
