@@ -89,7 +89,12 @@ int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed);
  * and image_ids[f] = f this is rl_deconv_simulate(h, rng_kind, s).                              */
 int rl_deconv_simulate_keyed(rl_deconv* h, int rng_kind, const uint64_t* seeds, const uint32_t* image_ids);
 /* Inject a measurement [batch][n_psf][ny][nx] instead (load_data_from_tif
- * :514-518, or noise drawn on the host with numpy for figure reproduction).  */
+ * :514-518, or noise drawn on the host with numpy for figure reproduction).
+ * New data (this call, rl_deconv_simulate, rl_deconv_simulate_keyed) starts a new Richardson-Lucy run: the
+ * next rl_deconv_iterate begins from ones and rl_deconv_get_estimate fails (RL_ERR_STATE) until then.  The
+ * reference keeps its estimate across create_data_from_object (:496-531, it only resets at num_iterations
+ * == 0); a caller that wants that reads the estimate before the new data and hands it back with
+ * rl_deconv_set_estimate afterwards -- the Deconvolver mirror does (line_sted_tools.py).                 */
 int rl_deconv_set_measurement(rl_deconv* h, const double* noisy);
 
 /* iterate (:520-531) K times; the first call starts from estimate = 1.       */
