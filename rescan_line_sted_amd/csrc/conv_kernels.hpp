@@ -384,7 +384,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 template <class Cfg, int M, int C, typename T, bool REALP = false, class Sync>
 RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "the core must be a wave-private transform");
-    static_assert(M == 2 || M == 4, "outer radix 2 or 4");
+    static_assert(M == 2 || M == 4 || M == 8, "outer radix 2, 4 or 8");
     constexpr int NP = Cfg::NP, Li = Cfg::L, L = M * Li, LP = LdsSlots<Cfg>::value;
     constexpr int NT = 64 * C;
     static_assert((Li * C) % NT == 0, "tile must divide evenly over the workgroup");

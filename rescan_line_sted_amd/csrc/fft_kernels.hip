@@ -105,13 +105,10 @@ __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && M
 }
 
 // ---- long column transforms on the wave-private core (conv_kernels.hpp colconv_outer_body) ----
-// L = 2304 = 4 x 576, f32: fft_configs.hpp OuterCol<L>.  The f64 kernel of the length stays the
-// workgroup-synchronous one (4 x 9 complex doubles per lane would not fit the register file).
-#ifndef RL_OUTER_MIN_WAVES
-#define RL_OUTER_MIN_WAVES 4
-#endif
+// L = 2304 = 4 x 576 and 4608 = 8 x 576, f32: fft_configs.hpp OuterCol<L>.  The f64 kernels of these lengths stay
+// the workgroup-synchronous ones (4 x 9 complex doubles per lane would not fit the register file).
 template <int L, int C, bool REALP>
-__global__ void __launch_bounds__(64 * C, RL_OUTER_MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
+__global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using OC = OuterCol<L>;

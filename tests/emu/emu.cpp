@@ -262,6 +262,8 @@ int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double
     if (Li == 256 && M == 4) return col_outer_t<C256, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     if (Li == 256 && M == 2) return col_outer_t<C256, 2, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     if (Li == 576 && M == 4) return col_outer_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    if (Li == 256 && M == 8) return col_outer_t<C256, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    if (Li == 576 && M == 8) return col_outer_t<C576, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     return -2;
 }
 

@@ -362,10 +362,10 @@ def test_streaming_bodies_l576_f32(emu):
 
 # ------------------------------------------------- long column transforms on the wave-private core
 @pytest.mark.parametrize('Li,M,ny,kx,real_psf', [(256, 4, 900, 11, 0), (256, 2, 437, 8, 1), (576, 4, 2048, 9, 0),
-                                                   (576, 4, 2001, 3, 1)])
+                                                   (576, 4, 2001, 3, 1), (256, 8, 1900, 5, 0), (576, 8, 4096, 2, 1)])
 def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
     """colconv_outer_body: L = M * Li as M core transforms plus one radix-M step in registers (the f32
-    column kernel of L = 2304 = 4 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat), rows < ny."""
+    column kernel of L = 2304 = 4 x 576 and 4608 = 8 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat), rows < ny."""
     if emu.emu_spec_blocked():
         pytest.skip('row-major spectra only')
     L, V, frames = M * Li, 2, 1

@@ -8,7 +8,7 @@ g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
 point = [g['2p0x_lr/point_sted_psf'][0]]
 line4 = [p[None] for p in g['2p0x_lr/line_sted_psfs'][:, 0]]
 for name, psfs, n, B, K, obj_seed in (('2048^2 point V=1 K=20', point, 2048, 16, 20, 1234), ('2048^2 line-rescan V=4 K=20', line4, 2048, 8, 20, 1234),
-                                      ('1024^2 point V=1 K=20', point, 1024, 64, 20, 99), ('4096^2 point V=1 K=100', point, 4096, 2, 100, 4321)):
+                                      ('1024^2 point V=1 K=20', point, 1024, 64, 20, 99), ('4096^2 point V=1 K=100', point, 4096, 8, 100, 4321)):
     obj = np.random.default_rng(obj_seed).random((n, n)) * 255
     plan = _lib.DeconvPlan(psfs, B, n, n, dtype='f32')
     plan.set_object(np.broadcast_to(obj, (B, n, n)), 5e10 * (n / 128) ** 2)

@@ -7,7 +7,7 @@ from rescan_line_sted_amd import _lib
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
 psf = list(g['2p0x_lr/point_sted_psf'])
 out = {'tag': os.environ.get('TAG', ''), 'rows': []}
-for size in (512, 2048):
+for size in (512, 1024, 2048):
     obj = np.random.default_rng(1234).random((1, size, size)) * 255
     p64 = _lib.DeconvPlan(psf, 1, size, size, dtype='f64'); p64.set_object(obj, 5e10 * (size // 128) ** 2); p64.simulate(seed=9)
     noisy = p64.measurement()
