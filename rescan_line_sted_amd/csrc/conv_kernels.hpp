@@ -375,13 +375,13 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 // class at a time -- 8 columns x 576 rows, the L = 576 kernel's 51 KB -- the M core results wait in
 // registers (M * 9 complex values per lane), and the core is the barrier-free wave-private transform.
 // Rows >= ny are zero on the way in and never stored (2048 of 2304: every residue class is the
-// 512-of-576 case of the L = 576 kernel).  COL_PER_IMAGE semantics.
+// 512-of-576 case of the L = 576 kernel).  MODE as in colconv_wave_body (COL_PER_IMAGE / COL_H_MULTI / COL_HT_SUM).
 // (Tried and measured slower, 907 vs 569 us per 16-frame launch at one workgroup per CU: decimation in frequency
 // over M blocks of contiguous rows with the core transforms chained forward -> multiply -> inverse in registers.
 // It loads all M blocks before the first transform and keeps all M x 9 values live through every core transform;
 // the residue-class form below interleaves loads and transforms and lets the live set grow with them.)
 // Twiddles: p.tw = [core table PassTw<Cfg>][ (M-1) x Li entries W_L^(q k), q = 1 .. M-1 ].
-template <class Cfg, int M, int C, typename T, bool REALP = false, class Sync>
+template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, class Sync>
 RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "the core must be a wave-private transform");
     static_assert(M == 2 || M == 4 || M == 8, "outer radix 2, 4 or 8");
@@ -399,14 +399,11 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     const int col0 = bx * C, col = col0 + w;
     const bool colok = col < p.kx;
     const size_t img = spec_image_elems(p.ny, p.pitch);
-    const int frame = by / p.V, view = by % p.V;
-    const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
-    cx<T>* __restrict__ out = p.out + (size_t)by * img;
     const cx<T>* __restrict__ ctw = p.tw + PassTw<Cfg, false, 0>::TOTAL;   // W_L^(q k) at (q - 1) * Li + k
     LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
 
     // residue class q of the tile: element e = tid + it*NT <-> (m = e / C, column c = e % C), row M*m + q
-    auto load_class = [&](int q) {
+    auto load_class = [&](const cx<T>* __restrict__ in, int q) {
         cx<T> x[NLD];
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -421,7 +418,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
             lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
         }
     };
-    auto store_class = [&](int q) {
+    auto store_class = [&](cx<T>* __restrict__ out, int q) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
@@ -436,67 +433,131 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     };
     auto slot_live = [&](int s) -> bool { return s == NV ? true : (lane + (s / FL::R) * 64) < FL::NBF; };
 
-    cx<T> Y[M][NV + 1];   // [q][slot]; slot NV = tail element (unused when the core has none)
+    using Regs = cx<T>[M][NV + 1];   // [q][slot]; slot NV = tail element (unused when the core has none)
+    // Y <- the M core transforms of the residue classes of image `in`; `first`: no workgroup is still reading LDS
+    auto forward_classes = [&](const cx<T>* __restrict__ in, Regs& Y, bool first) {
 #pragma unroll
-    for (int q = 0; q < M; ++q) {
-        if (q > 0) sync.wg();          // every wave is done with the previous class in LDS
-        load_class(q);
-        sync.wg();
-        cx<T> v[VMAX];
-        cx<T> tl = mk<T>((T)0, (T)0);
-        if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+        for (int q = 0; q < M; ++q) {
+            if (q > 0 || !first) sync.wg();          // every wave is done with the previous class in LDS
+            load_class(in, q);
+            sync.wg();
+            cx<T> v[VMAX];
+            cx<T> tl = mk<T>((T)0, (T)0);
+            if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
 #pragma unroll
-        for (int s = 0; s < NV; ++s) Y[q][s] = v[s];
-        Y[q][NV] = tl;
-    }
-    if (colok) {
+            for (int s = 0; s < NV; ++s) Y[q][s] = v[s];
+            Y[q][NV] = tl;
+        }
+    };
+    // per register slot: X[k + Li j] = radix-M butterfly of the twiddled core results, times psf_hat[view]
+    auto slot_spectrum = [&](const Regs& Y, int s, int view, cx<T> (&u)[M]) {
+        const int k = slot_index(s);
         const size_t pcol = ((size_t)view * p.kx + col) * L;
+        u[0] = Y[0][s];
 #pragma unroll
-        for (int s = 0; s <= NV; ++s) {
-            if (s == NV && !FL::TAIL) continue;
-            if (!slot_live(s)) continue;
-            const int k = slot_index(s);
-            cx<T> u[M];
-            u[0] = Y[0][s];
+        for (int q = 1; q < M; ++q) u[q] = cmul(Y[q][s], ctw[(q - 1) * Li + k]);
+        dft<M, false>(u);                                   // u[j] = X[k + Li j]
 #pragma unroll
-            for (int q = 1; q < M; ++q) u[q] = cmul(Y[q][s], ctw[(q - 1) * Li + k]);
-            dft<M, false>(u);                                   // u[j] = X[k + Li j]
+        for (int j = 0; j < M; ++j) {
+            if constexpr (REALP) u[j] = scale(u[j], p.psf_hat_re[pcol + k + Li * j]);
+            else u[j] = cmul(u[j], p.psf_hat[pcol + k + Li * j]);
+        }
+    };
+    // the way back: Z_q[k] = conj(W_L^(q k)) * sum_j conj(W_M)^(q j) X[k + Li j]
+    auto slot_classes = [&](cx<T> (&u)[M], int s, Regs& Z) {
+        const int k = slot_index(s);
+        dft<M, true>(u);
+        Z[0][s] = u[0];
 #pragma unroll
-            for (int j = 0; j < M; ++j) {
-                if constexpr (REALP) u[j] = scale(u[j], p.psf_hat_re[pcol + k + Li * j]);
-                else u[j] = cmul(u[j], p.psf_hat[pcol + k + Li * j]);
+        for (int q = 1; q < M; ++q) {
+            const cx<T> t = ctw[(q - 1) * Li + k];
+            Z[q][s] = cmul(u[q], mk<T>(t.re, -t.im));
+        }
+    };
+    // inverse core transforms of the M classes, each stored as soon as it is back in LDS
+    auto inverse_classes = [&](const Regs& Z, cx<T>* __restrict__ out) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            sync.wg();                     // LDS free: the previous class is stored (or the forward transforms are done)
+            if (colok) {
+                cx<T> v[VMAX];
+#pragma unroll
+                for (int s = 0; s < NV; ++s) v[s] = Z[q][s];
+                cx<T> tl = Z[q][NV];
+                run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
+                sync.wave();   // last pass' LDS reads are done before the column is overwritten
+#pragma unroll
+                for (int nb = 0; nb < IL::NB; ++nb) {
+                    const int j = lane + nb * 64;
+                    if (j < IL::NBF) {
+#pragma unroll
+                        for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
+                    }
+                }
             }
-            dft<M, true>(u);                                    // u[q] = sum_j conj(W_M)^(q j) X[k + Li j]
-            Y[0][s] = u[0];
-#pragma unroll
-            for (int q = 1; q < M; ++q) {
-                const cx<T> t = ctw[(q - 1) * Li + k];
-                Y[q][s] = cmul(u[q], mk<T>(t.re, -t.im));
+            sync.wg();
+            store_class(out, q);
+        }
+    };
+#define RL_FOR_LIVE_SLOTS(s)                                  \
+    _Pragma("unroll") for (int s = 0; s <= NV; ++s)           \
+        if ((s != NV || FL::TAIL) && slot_live(s))
+
+    if constexpr (MODE == COL_PER_IMAGE) {
+        const int frame = by / p.V, view = by % p.V;
+        Regs Y;
+        forward_classes(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img, Y, true);
+        if (colok) {
+            RL_FOR_LIVE_SLOTS(s) {
+                cx<T> u[M];
+                slot_spectrum(Y, s, view, u);
+                slot_classes(u, s, Y);
             }
         }
-    }
+        inverse_classes(Y, p.out + (size_t)by * img);
+    } else if constexpr (MODE == COL_H_MULTI) {
+        // by = frame: ONE forward transform of the frame's spectrum, V products + inverse transforms (the radix-M
+        // butterfly is recomputed per view: M log M adds against keeping a second M x NV register set alive)
+        Regs Y, Z;
+        forward_classes(p.in + (size_t)by * img, Y, true);
+        for (int view = 0; view < p.V; ++view) {
+            if (colok) {
+                RL_FOR_LIVE_SLOTS(s) {
+                    cx<T> u[M];
+                    slot_spectrum(Y, s, view, u);
+                    slot_classes(u, s, Z);
+                }
+            }
+            inverse_classes(Z, p.out + ((size_t)by * p.V + view) * img);
+        }
+    } else {   // COL_HT_SUM: the V products are summed in the Fourier domain, one inverse transform (see colconv_wave_body)
+        Regs Y, A;
 #pragma unroll
-    for (int q = 0; q < M; ++q) {
-        sync.wg();                     // LDS free: the previous class is stored (or the forward transforms are done)
-        if (colok) {
-            cx<T> v[VMAX];
+        for (int j = 0; j < M; ++j)
 #pragma unroll
-            for (int s = 0; s < NV; ++s) v[s] = Y[q][s];
-            cx<T> tl = Y[q][NV];
-            run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
-            sync.wave();   // last pass' LDS reads are done before the column is overwritten
+            for (int s = 0; s <= NV; ++s) A[j][s] = mk<T>((T)0, (T)0);
+        for (int view = 0; view < p.V; ++view) {
+            forward_classes(p.in + ((size_t)by * p.V + view) * img, Y, view == 0);
+            if (colok) {
+                RL_FOR_LIVE_SLOTS(s) {
+                    cx<T> u[M];
+                    slot_spectrum(Y, s, view, u);
 #pragma unroll
-            for (int nb = 0; nb < IL::NB; ++nb) {
-                const int j = lane + nb * 64;
-                if (j < IL::NBF) {
-#pragma unroll
-                    for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
+                    for (int j = 0; j < M; ++j) A[j][s] = A[j][s] + u[j];
                 }
             }
         }
-        sync.wg();
-        store_class(q);
+        if (colok) {
+            RL_FOR_LIVE_SLOTS(s) {
+                cx<T> u[M];
+#pragma unroll
+                for (int j = 0; j < M; ++j) u[j] = A[j][s];
+                slot_classes(u, s, A);
+            }
+        }
+        inverse_classes(A, p.out + (size_t)by * img);
     }
+#undef RL_FOR_LIVE_SLOTS
 }
 
 // -------------------------------- row pass ---------------------------------

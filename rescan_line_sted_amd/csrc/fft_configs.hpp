@@ -147,6 +147,7 @@ struct OuterCol {
     static constexpr bool value = false;
     using Core = typename CfgFor<64>::Cfg;   // unused
     static constexpr int M = 2, C = 8, MIN_WAVES = 1;
+    static constexpr bool MULTI = false;
 };
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
@@ -159,11 +160,21 @@ struct OuterCol {
 #ifndef RL_OUTER_MIN_WAVES
 #define RL_OUTER_MIN_WAVES 4
 #endif
+// The multi-view column modes on the outer-decimation body (COL_H_MULTI: one forward transform, V products and inverse
+// transforms; COL_HT_SUM: V forward transforms summed before one inverse) hold two 4 x 10 register sets: 256 VGPRs + 81 spilled
+// dwords, one workgroup per CU.  Measured at 2048^2, 4 views, per 4-frame launch: H 0.355 -> 0.478 ms, H_t 0.354 -> 0.525 ms,
+// ROW_UPDATE 0.193 -> 0.069 ms (one spectrum instead of four); bench.py --size 2048: 186-189 -> 172 frames/s.  The 37 % of
+// column traffic they save does not pay for the halved occupancy: OFF (the per-image kernel runs V times per frame); the
+// host emulation keeps testing the modes (test_outer_decimation_multi_view_modes).
+#ifndef RL_OUTER_MULTI
+#define RL_OUTER_MULTI 0
+#endif
 template <>
 struct OuterCol<2304> {
     static constexpr bool value = RL_OUTER_2304 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
+    static constexpr bool MULTI = RL_OUTER_MULTI != 0;   // COL_H_MULTI / COL_HT_SUM kernels (two M x 10 register sets)
 };
 // 1152 = 2 x 576 and 4608 = 8 x 576 on the same body: 2 x 10 / 8 x 10 complex values wait in registers.
 // Measured (us per 512^2-equivalent frame, column kernel alone; whole 20-iteration loop):
@@ -184,12 +195,14 @@ struct OuterCol<1152> {
     static constexpr bool value = RL_OUTER_1152 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 2, C = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
+    static constexpr bool MULTI = false;
 };
 template <>
 struct OuterCol<4608> {
     static constexpr bool value = RL_OUTER_4608 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 8, C = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
+    static constexpr bool MULTI = false;                 // (two 8 x 10 register sets do not fit)
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

@@ -107,8 +107,10 @@ __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && M
 // ---- long column transforms on the wave-private core (conv_kernels.hpp colconv_outer_body) ----
 // L = 2304 = 4 x 576 and 4608 = 8 x 576, f32: fft_configs.hpp OuterCol<L>.  The f64 kernels of these lengths stay
 // the workgroup-synchronous ones (4 x 9 complex doubles per lane would not fit the register file).
-template <int L, int C, bool REALP>
-__global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
+// MODE: COL_PER_IMAGE, or -- outer radix <= 4 -- the multi-view modes, which hold two M x 10 register sets (one 8-wave
+// workgroup per CU, like the radix-8 kernel)
+template <int L, int C, bool REALP, int MODE = COL_PER_IMAGE>
+__global__ void __launch_bounds__(64 * C, MODE == COL_PER_IMAGE ? OuterCol<L>::MIN_WAVES : 2) k_colconv_outer(const ColParams<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using OC = OuterCol<L>;
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_oute
         bx = w % gx;
         by = w / gx;
     }
-    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
+    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
 }
 template <int L>
 static void fill_outer_twiddles(double* out) {
@@ -380,9 +382,21 @@ static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigne
         if (dtype == DT_F32) {
             using OC = OuterCol<RL_CFG_L>;
             const ColParams<float>& p = *static_cast<const ColParams<float>*>(params);
-            if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
             constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
             const dim3 grid((unsigned)((p.kx + OC::C - 1) / OC::C), gy), block(64 * OC::C);
+            if constexpr (OC::MULTI) {
+                if (p.mode == COL_H_MULTI) {
+                    if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_H_MULTI>, grid, block, lds, s, p);
+                    else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_H_MULTI>, grid, block, lds, s, p);
+                    return hipGetLastError();
+                }
+                if (p.mode == COL_HT_SUM) {
+                    if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_HT_SUM>, grid, block, lds, s, p);
+                    else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_HT_SUM>, grid, block, lds, s, p);
+                    return hipGetLastError();
+                }
+            }
+            if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
             if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds, s, p);
             else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false>, grid, block, lds, s, p);
             return hipGetLastError();
@@ -430,6 +444,12 @@ static hipError_t prepare() {
         constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds)) != hipSuccess) return e;
+        if constexpr (OC::MULTI) {
+            if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_H_MULTI>, lds)) != hipSuccess) return e;
+            if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_H_MULTI>, lds)) != hipSuccess) return e;
+            if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_HT_SUM>, lds)) != hipSuccess) return e;
+            if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_HT_SUM>, lds)) != hipSuccess) return e;
+        }
     }
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
@@ -454,7 +474,7 @@ const KernelTable* RL_TABLE_FN() {
     constexpr bool OUTER = OuterCol<RL_CFG_L>::value;
     constexpr int WP = WavePrivate<CCfg>::value ? 1 : 0;
     static const KernelTable t = {Cfg::L, Cfg::T, {OUTER ? OuterCol<RL_CFG_L>::C : kC32, kC64}, {kQ32, kQ64},
-                                  {OUTER ? 1 : WP, WP}, {WP, WP},
+                                  {OUTER ? 1 : WP, WP}, {OUTER ? (OuterCol<RL_CFG_L>::MULTI ? 1 : 0) : WP, WP},
                                   PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
                                   {OuterTw<RL_CFG_L, OUTER>::count, PassTw<CCfg, false, 0>::TOTAL},
                                   {OuterTw<RL_CFG_L, OUTER>::fill, fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,

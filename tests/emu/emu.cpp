@@ -226,7 +226,7 @@ int emu_row_f32(int L, int mode, const float* spec_in, float* spec_out, const fl
 }  // extern "C"
 template <class Core, int M, typename T>
 static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
-                       int in_sb, int in_sv) {
+                       int in_sb, int in_sv, int mode = COL_PER_IMAGE) {
     constexpr int C = 8, L = M * Core::L;
     constexpr int n_core = PassTw<Core, false, 0>::TOTAL;
     std::vector<double> h(2 * (size_t)(n_core + (M - 1) * Core::L));
@@ -246,11 +246,20 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
     p.psf_hat_re = real_psf ? psf_hat : nullptr;
     p.tw = tw.data();
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
-    p.mode = COL_PER_IMAGE; p.images = frames * V; p.order = 1;
-    run_grid((kx + C - 1) / C, frames * V, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
+    p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
+    run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
-                 if (real_psf) colconv_outer_body<Core, M, C, T, true>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
-                 else colconv_outer_body<Core, M, C, T, false>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 cx<T>* l = reinterpret_cast<cx<T>*>(lds);
+                 if (mode == COL_H_MULTI) {
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_H_MULTI>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_H_MULTI>(p, tid, bx, by, l, s);
+                 } else if (mode == COL_HT_SUM) {
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_HT_SUM>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_HT_SUM>(p, tid, bx, by, l, s);
+                 } else {
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false>(p, tid, bx, by, l, s);
+                 }
              });
     return 0;
 }
@@ -264,6 +273,17 @@ int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double
     if (Li == 576 && M == 4) return col_outer_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     if (Li == 256 && M == 8) return col_outer_t<C256, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     if (Li == 576 && M == 8) return col_outer_t<C576, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    return -2;
+}
+// the multi-view modes of the same body (M = 4): mode 1 = COL_H_MULTI (in [frames], out [frames*V]), 2 = COL_HT_SUM
+// (in [frames*V], out [frames])
+int emu_col_outer_multi_f64(int Li, int mode, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
+                            int pitch, int V, int frames) {
+    using C256 = CfgFor<256>::Cfg;
+    using C576 = CfgFor<576>::Cfg;
+    if (mode != COL_H_MULTI && mode != COL_HT_SUM) return -2;
+    if (Li == 256) return col_outer_t<C256, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, 1, 0, mode);
+    if (Li == 576) return col_outer_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, 1, 0, mode);
     return -2;
 }
 

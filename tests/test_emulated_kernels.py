@@ -385,3 +385,35 @@ def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
         for v in range(V):
             ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L     # the kernels leave the 1/L to psf_hat's scale
             assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
+
+
+@pytest.mark.parametrize('Li,mode,ny,kx,real_psf', [(256, 1, 901, 9, 0), (256, 2, 600, 3, 1), (576, 1, 2048, 2, 1), (576, 2, 2040, 2, 0)])
+def test_outer_decimation_multi_view_modes(emu, Li, mode, ny, kx, real_psf):
+    """The multi-view modes of colconv_outer_body (M = 4): COL_H_MULTI -- one forward transform feeds the V products
+    and inverse transforms -- and COL_HT_SUM -- the V products are summed before one inverse transform."""
+    if emu.emu_spec_blocked():
+        pytest.skip('row-major spectra only')
+    M, V, frames = 4, 3, 2
+    L = M * Li
+    pitch = (kx + 7) // 8 * 8
+    rng = np.random.default_rng(Li + mode + ny)
+    n_in = frames if mode == 1 else frames * V
+    n_out = frames * V if mode == 1 else frames
+    x = np.zeros((n_in, ny, pitch), dtype=np.complex128)
+    x[:, :, :kx] = rng.standard_normal((n_in, ny, kx)) + 1j * rng.standard_normal((n_in, ny, kx))
+    ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
+    out = np.zeros((n_out, ny, pitch), dtype=np.complex128)
+    psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
+    rc = emu.emu_col_outer_multi_f64(Li, mode, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames)
+    assert rc == 0
+    full = np.zeros((n_in, L, kx), dtype=np.complex128)
+    full[:, :ny] = x[:, :, :kx]
+    spec = np.fft.fft(full, axis=1)
+    for f in range(frames):
+        if mode == 1:
+            for v in range(V):
+                ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L
+                assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
+        else:
+            ref = np.fft.ifft(sum(spec[f * V + v] * ph[v].T for v in range(V)), axis=0)[:ny] * L
+            assert max_rel(out[f][:, :kx], ref) < 1e-12, f
