@@ -505,6 +505,7 @@ struct rl_deconv {
     int ensure_lanes() {
         if (fork) return RL_OK;
         HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        // (equal priorities: lane 0 at the highest stream priority and lane 1 at the lowest measured 17.2 k against 18.1 k frames/s)
         for (int l = 0; l < lanes; ++l) {
             HIP_TRY(hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&lane_done[l], hipEventDisableTiming));
