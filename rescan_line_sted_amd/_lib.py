@@ -156,15 +156,37 @@ class Context:
         check(lib.rl_ctx_synchronize(self.handle))
 
 
+def common_psf_shape(psfs):
+    """The reference convolves with each PSF on its own (fftconvolve(x, psf, mode='same'), ref:573,585), so the
+    PSFs of one Deconvolver may differ in shape; a plan holds one (V, py, px) stack.  Every PSF is embedded in
+    zeros of a common odd shape with its 'same'-mode centre (n - 1) // 2 on the common centre: the convolution
+    is unchanged."""
+    if all(p.shape == psfs[0].shape for p in psfs):
+        return psfs
+    half = [0, 0]
+    for p in psfs:
+        for ax in (0, 1):
+            n = p.shape[1 + ax]
+            c = (n - 1) // 2
+            half[ax] = max(half[ax], c, n - 1 - c)
+    out = []
+    for p in psfs:
+        q = np.zeros((1, 2 * half[0] + 1, 2 * half[1] + 1))
+        oy, ox = half[0] - (p.shape[1] - 1) // 2, half[1] - (p.shape[2] - 1) // 2
+        q[0, oy:oy + p.shape[1], ox:ox + p.shape[2]] = p[0]
+        out.append(q)
+    return out
+
+
 class DeconvPlan:
     """rl_deconv: `batch` frames sharing one PSF set and one image shape."""
 
     def __init__(self, psfs, batch, ny, nx, dtype='f32', device=0):
         psfs = [as_f64(p) for p in psfs]
         for p in psfs:
-            if p.ndim != 3 or p.shape[0] != 1 or p.shape != psfs[0].shape:
-                raise ValueError('PSFs must all have the same shape (1, py, px); got %s'
-                                 % [q.shape for q in psfs])
+            if p.ndim != 3 or p.shape[0] != 1:
+                raise ValueError('PSFs must have shape (1, py, px); got %s' % [q.shape for q in psfs])
+        psfs = common_psf_shape(psfs)
         self.ctx = Context.get(device)
         self.psf_stack = as_f64(np.concatenate(psfs, axis=0))
         self.V, self.py, self.px = self.psf_stack.shape

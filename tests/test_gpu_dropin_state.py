@@ -119,3 +119,51 @@ def test_pinned_host_arrays_and_out_argument(st, views, obj):
     with pytest.raises(ValueError):
         plan.estimate(out=np.empty(3))
     del frames, out, got                 # the blocks are released with their last views
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_method_sequences_match_the_reference_class(st, seed, tmp_path):
+    """The mirror class and the oracle's restatement of the reference class driven through the same random
+    sequence of calls (new data after iterations, estimate assignment, H / H_t on the data's and on other
+    shapes, restarts through num_iterations = 0) hold the same estimate throughout."""
+    rng = np.random.default_rng(500 + seed)
+    V = int(rng.integers(1, 4))
+    psfs = [(rng.random((1, int(rng.integers(1, 8)) * 2 + 1, 9)) + 0.05) for _ in range(V)]
+    psfs = [p / p.sum() for p in psfs]
+    shape = (int(rng.integers(1, 3)), int(rng.integers(8, 40)), int(rng.integers(8, 48)))
+    d = st.Deconvolver(psfs, str(tmp_path) + '/', verbose=False)
+    o = orc.Deconvolver(psfs)
+    have_data = False
+    log = []
+    for step in range(16):
+        op = str(rng.choice(['data', 'iterate', 'iterate', 'iterate', 'H', 'H_other', 'H_t', 'assign', 'restart']))
+        if not have_data and op not in ('data', 'H', 'H_other'):
+            op = 'data'
+        log.append(op)
+        if op == 'data':
+            obj = rng.random(shape) * 10
+            s = int(rng.integers(0, 1000))
+            d.create_data_from_object(obj, 2e5, random_seed=s)
+            o.create_data_from_object(obj, 2e5, noisy_measurement=d.noisy_measurement)
+            assert all(max_rel(a, b) < 1e-12 for a, b in zip(d.noiseless_measurement, o.noiseless_measurement)), log
+            have_data = True
+        elif op == 'iterate':
+            d.iterate()
+            o.iterate()
+            assert d.num_iterations == o.num_iterations
+        elif op in ('H', 'H_other'):
+            sh = shape if op == 'H' else (1, shape[1] + 3, shape[2] + 5)
+            x = rng.random(sh)
+            assert all(max_rel(a, b) < 1e-12 for a, b in zip(d.H(x), o.H(x))), log
+        elif op == 'H_t':
+            y = [rng.random(shape) + 0.1 for _ in range(V)]
+            assert max_rel(d.H_t(y), o.H_t(y)) < 1e-12, log
+        elif op == 'assign' and d.num_iterations > 0:
+            e = rng.random(shape) + 0.5
+            d.estimate = e
+            o.estimate = e.copy()
+        elif op == 'restart':
+            d.num_iterations = 0
+            o.num_iterations = 0
+        if d.num_iterations > 0:
+            assert max_rel(d.estimate, o.estimate) < 1e-10, log

@@ -145,3 +145,19 @@ def test_pmc_traffic_json_is_what_the_tool_makes_of_the_committed_counter_files(
     # the doubled FETCH_SIZE reproduces the bytes rowpass_FWD must read to within 1 %
     cal = committed['_calibration']
     assert abs(2 * cal['rowpass_FWD_fetch_reported_bytes'] / cal['rowpass_FWD_must_read_bytes'] - 1) < 0.01
+
+
+def test_psfs_of_different_shapes_are_embedded_on_a_common_centre():
+    """One plan holds one (V, py, px) stack; the reference convolves with each PSF on its own (ref:573,585).
+    The centred zero embedding leaves the 'same'-mode convolution unchanged (odd, even, 1-wide shapes)."""
+    from rescan_line_sted_amd import _lib
+    from oracle import line_sted_oracle as orc
+    rng = np.random.default_rng(0)
+    psfs = [rng.random((1, 4, 9)), rng.random((1, 7, 2)), rng.random((1, 1, 6))]
+    x = rng.random((2, 20, 23))
+    common = _lib.common_psf_shape(psfs)
+    assert len({q.shape for q in common}) == 1 and common[0].shape[1] % 2 == 1 and common[0].shape[2] % 2 == 1
+    for p, q in zip(psfs, common):
+        assert np.abs(orc.conv_same(x, p) - orc.conv_same(x, q)).max() < 1e-13
+    same = [rng.random((1, 5, 5)) for _ in range(2)]
+    assert _lib.common_psf_shape(same) is same
