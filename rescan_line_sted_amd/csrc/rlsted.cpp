@@ -1292,6 +1292,7 @@ int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, doubl
     if (!h || !avg_ms) return fail(RL_ERR_INVALID, "NULL argument");
     if (!h->have_obj) return fail(RL_ERR_STATE, "rl_deconv_set_object has not been called");
     if (k < 0) return fail(RL_ERR_INVALID, "k < 0");
+    if (h->sep) return fail(RL_ERR_UNSUPPORTED, "per-kernel timing covers the FFT strategy; this plan runs the separable stencils");
     HIP_TRY(hipSetDevice(h->ctx->device));
     HIP_TRY(hipDeviceSynchronize());
     h->timed.clear();
@@ -1323,6 +1324,7 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
     if (!h || !avg_ms) return fail(RL_ERR_INVALID, "NULL argument");
     if (!h->have_meas) return fail(RL_ERR_STATE, "no measurement");
     if (reps < 1) return fail(RL_ERR_INVALID, "reps < 1");
+    if (h->sep) return fail(RL_ERR_UNSUPPORTED, "per-kernel timing covers the FFT strategy; this plan runs the separable stencils");
     HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
     if (!h->est_ready) RL_TRY(h->start_estimate());

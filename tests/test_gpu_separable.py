@@ -120,6 +120,11 @@ def test_strategy_choice(lib, golden):
     small = planes([np.outer(gauss(7, 1.0), gauss(5, 2.0))])                 # automatic choice: rank 1 and py + px <= 16
     assert plan_with(lib, 1, small, 1, 64, 64).strategy()['separable']
     assert not plan_with(lib, 1, planes(rank1_views('two_lines')), 1, 64, 64).strategy()['separable']   # 17 + 17 taps: FFT is faster
+    sp = plan_with(lib, 1, small, 1, 64, 64)
+    sp.set_object(np.ones((1, 64, 64)), 1e6)
+    sp.simulate(seed=1)
+    with pytest.raises(lib.RlstedError):                                      # per-kernel timing is the FFT strategy's
+        sp.time_kernels(2)
     blob = np.outer(gauss(9, 2), gauss(9, 2)) + np.eye(9) * 0.01             # small, full rank
     assert not plan_with(lib, 2, planes([blob]), 1, 64, 64).strategy()['separable']
 
