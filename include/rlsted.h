@@ -137,8 +137,10 @@ int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements
  * is rank 1 (p = u v^T; the 0 / 90 degree line PSFs) and small, H / H_t run as direct row + column stencils;
  * otherwise the FFT path, with real_psf_spectrum != 0 when the (point-symmetric) PSFs' spectra are real and
  * the column kernels multiply by their real parts alone; fused_rl != 0: RLSTED_FUSED selected the persistent
- * XCD-resident Richardson-Lucy kernel.  Any of the pointers may be NULL.            */
-int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl);
+ * XCD-resident Richardson-Lucy kernel; frame_pairs != 0: the Richardson-Lucy loop transforms frames 2p and 2p+1
+ * as the real and imaginary part of one complex image (single view, even batch, f32 by default: RLSTED_PAIR) --
+ * a frame's estimate then depends on its partner at rounding level.  Any of the pointers may be NULL.      */
+int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl, int* frame_pairs);
 
 /* Plan geometry: frames per plan, views per frame, image shape.                */
 int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx);

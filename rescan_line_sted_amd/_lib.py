@@ -50,7 +50,7 @@ PROTOTYPES = {
     'rl_deconv_device_ptr': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_c.c_size_t), _c.POINTER(_i)]),
     'rl_host_alloc': (_i, [_c.c_size_t, _c.POINTER(_vp)]),
     'rl_host_free': (_i, [_vp]),
-    'rl_deconv_strategy': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    'rl_deconv_strategy': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_deconv_dims': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_batch_run': (_i, [_vp, _vp, _i, _i, _i, _dp]),
     'rl_comm_unique_id': (_i, [_vp]),
@@ -209,9 +209,10 @@ class DeconvPlan:
         return {'ly': ly.value, 'lx': lx.value, 'pitch': pitch.value, 'device_bytes': nbytes.value}
 
     def strategy(self):
-        a, b, c = _i(), _i(), _i()
-        check(lib.rl_deconv_strategy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        return {'separable': bool(a.value), 'real_psf_spectrum': bool(b.value), 'fused_rl': bool(c.value)}
+        a, b, c, d = _i(), _i(), _i(), _i()
+        check(lib.rl_deconv_strategy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+        return {'separable': bool(a.value), 'real_psf_spectrum': bool(b.value), 'fused_rl': bool(c.value),
+                'frame_pairs': bool(d.value)}
 
     def set_object(self, obj, total_brightness=None):
         obj = as_f64(obj).reshape(self.B, self.ny, self.nx)

@@ -1165,4 +1165,106 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     row_item<Cfg, MODE, RL_LEAN_NRM_EARLY != 0>(p, t, (int)t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync, [] {});
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Frame pairs: TWO FRAMES ride through one complex image -- frame 2p in the real part, frame 2p+1 in the imaginary
+// part.  The PSF is real, so  IFFT2(FFT2(a + i b) * psf_hat) = conv(a, psf) + i conv(b, psf):  the row kernels
+// transform whole complex rows of the pair and there is no Hermitian packing in front of the inverse transform
+// and no splitting behind the forward one (rowpass_body / row_item do both around every transform, through LDS).
+// The spectrum of a pair is [ny][L] complex, full width -- 576 columns against 2 x 289 for the two frames -- and the
+// column kernels run on it unchanged (kx = pitch = L, psf_hat at full width).  One wave = one row of one pair:
+//   ROW_FWD     spec_out = rowFFT(src[2p] + i src[2p+1])                            (the spectrum of the estimate)
+//   ROW_RATIO   z = rowIFFT(spec_in); spec_out = rowFFT(meas_a / max(Re z, 0) + i meas_b / max(Im z, 0))
+//   ROW_UPDATE  z = rowIFFT(spec_in); est_a *= max(Re z, 0) / norm, est_b *= max(Im z, 0) / norm; spec_out = rowFFT(est)
+// The spectrum row is loaded straight into the register layout the first inverse pass takes (the layout the last forward
+// pass leaves: that is what lets FFT -> pointwise -> IFFT chain in the column kernel) and stored from it.
+// Single view, wave-private lengths; an odd frame count leaves the last pair's imaginary part empty.
+template <class Cfg, int Q, int MODE, typename T, class Sync>
+RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "pair rows need wave-private transforms");
+    static_assert(!RL_SPEC_BLOCKED, "row-major spectra only");
+    static_assert(MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE, "pair modes");
+    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value, VMAX = CfgRegs<Cfg>::VMAX;
+    using I0 = PassInfo<Cfg, true, 0>;        // spectrum side, on the way in
+    using F0 = PassInfo<Cfg, false, 0>;       // image side
+    using FL = PassInfo<Cfg, false, NP - 1>;  // spectrum side, on the way out
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    static_assert(I0::R == FL::R && I0::NBF == FL::NBF && I0::TAIL == FL::TAIL && I0::NBM == FL::NBM, "spectrum-side layouts must agree");
+    static_assert(IL::R == F0::R && IL::NB == F0::NB && !F0::TAIL, "image-side layouts must agree");
+    constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
+    const int q = rl_uniform(tid / 64);
+    const int t = tid % 64;
+    const int row = bx * Q + q;
+    if (row >= p.ny) return;   // whole wave; no workgroup barrier below
+    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + q * LP};
+    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
+    const bool okb = 2 * by + 1 < p.frames;
+    const size_t ra = ((size_t)(2 * by) * p.ny + row) * p.nx, rb = okb ? ra + rimg : ra;   // frame a / b, this row
+    const int tail_k = (64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF;
+
+    // operands of the pointwise stage, requested ahead of the inverse transform
+    cx<T> pre[NB * R], nrm[MODE == ROW_UPDATE ? NB * R : 1];
+    {
+        const T* __restrict__ s0 = (MODE == ROW_UPDATE ? p.dst : p.src) + ra;
+        const T* __restrict__ s1 = (MODE == ROW_UPDATE ? p.dst : p.src) + rb;
+        const T* __restrict__ n0 = p.norm + (size_t)row * p.nx;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = (t + nb * 64) + r * NBF;
+                const bool inx = (t + nb * 64) < NBF && i < p.nx;
+                pre[nb * R + r] = inx ? mk<T>(s0[i], s1[i]) : mk<T>((T)0, (T)0);
+                if constexpr (MODE == ROW_UPDATE) nrm[nb * R + r] = inx ? mk<T>(n0[i], n0[i]) : mk<T>((T)1, (T)1);
+            }
+    }
+    cx<T> v[VMAX];
+    cx<T> tl = mk<T>((T)0, (T)0);
+    if constexpr (MODE != ROW_FWD) {
+        const cx<T>* __restrict__ si = p.spec_in + (size_t)(p.in_mod > 0 ? by % p.in_mod : by) * simg + (size_t)row * p.pitch;
+#pragma unroll
+        for (int nb = 0; nb < I0::NBM; ++nb)
+#pragma unroll
+            for (int r = 0; r < I0::R; ++r) {
+                const int j = t + nb * 64;
+                v[nb * I0::R + r] = j < I0::NBF ? rl_ldg(sync, si + (j + r * I0::NBF)) : mk<T>((T)0, (T)0);
+            }
+        if constexpr (I0::TAIL) tl = rl_ldg(sync, si + tail_k);
+        run_passes<Cfg, true, 0, true>(v, tl, t, view_lds, p.tw, sync);
+    }
+#pragma unroll
+    for (int s = 0; s < NB * R; ++s) {
+        const int nb = s / R, r = s % R;
+        const int i = (t + nb * 64) + r * NBF;
+        const bool inx = (t + nb * 64) < NBF && i < p.nx;
+        cx<T> z = mk<T>((T)0, (T)0);
+        if constexpr (MODE == ROW_FWD) {
+            z = mk<T>(pre[s].re, okb ? pre[s].im : (T)0);
+        } else {
+            const T e0 = v[s].re > (T)0 ? v[s].re : (T)0, e1 = v[s].im > (T)0 ? v[s].im : (T)0;
+            if constexpr (MODE == ROW_RATIO) {
+                z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
+                z.im = inx && okb ? rl_div(pre[s].im, e1) : (T)0;
+            } else {
+                z.re = inx ? pre[s].re * rl_div(e0, nrm[s].re) : (T)0;
+                z.im = inx && okb ? pre[s].im * rl_div(e1, nrm[s].im) : (T)0;
+                if (inx) p.dst[ra + i] = z.re;
+                if (inx && okb) p.dst[rb + i] = z.im;
+            }
+        }
+        v[s] = z;
+    }
+    if constexpr (MODE != ROW_FWD) fft_sync<Cfg>(sync);   // the inverse's last LDS reads are done
+    run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
+    cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg + (size_t)row * p.pitch;
+#pragma unroll
+    for (int nb = 0; nb < FL::NBM; ++nb)
+#pragma unroll
+        for (int r = 0; r < FL::R; ++r) {
+            const int j = t + nb * 64;
+            if (j < FL::NBF) so[j + r * FL::NBF] = rl_spec_round(v[nb * FL::R + r], p.qscale);
+        }
+    if constexpr (FL::TAIL) so[tail_k] = rl_spec_round(tl, p.qscale);
+}
+
 }  // namespace rl

@@ -354,6 +354,31 @@ static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hip
     return hipGetLastError();
 }
 
+// frame-pair row kernels (rowpair_body)
+template <int L, int Q, int MODE, typename T>
+__global__ void __launch_bounds__(64 * Q, (row_min_waves<L, MODE == ROW_FWD ? ROW_RATIO : MODE, true, T>())) k_rowpair(const RowParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevSync s;
+    using KCfg = typename CfgFor<L>::Cfg;
+    if constexpr (WavePrivate<KCfg>::value)
+        rowpair_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+}
+template <int Q, typename T>
+static hipError_t launch_row_pair_t(int mode, const void* params, unsigned gy, hipStream_t s) {
+    if constexpr (WavePrivate<Cfg>::value) {
+        const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
+        const dim3 grid((unsigned)((p.ny + Q - 1) / Q), gy), block(64 * Q);
+        const size_t lds = (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>);
+        if (mode == ROW_FWD) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_FWD, T>, grid, block, lds, s, p);
+        else if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T>, grid, block, lds, s, p);
+        else if (mode == ROW_UPDATE) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T>, grid, block, lds, s, p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
 template <int Q, int MODE, typename T>
 static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
@@ -410,6 +435,10 @@ static hipError_t launch_row(int dtype, int mode, const void* params, unsigned g
     return dtype == DT_F32 ? launch_row_t<kQ32, float>(mode, params, gx, gy, s)
                            : launch_row_t<kQ64, double>(mode, params, gx, gy, s);
 }
+static hipError_t launch_row_pair(int dtype, int mode, const void* params, unsigned gy, hipStream_t s) {
+    return dtype == DT_F32 ? launch_row_pair_t<kQ32, float>(mode, params, gy, s)
+                           : launch_row_pair_t<kQ64, double>(mode, params, gy, s);
+}
 
 template <typename F>
 static hipError_t allow_lds(F* fn, size_t bytes) {
@@ -428,6 +457,11 @@ static hipError_t prepare_rows() {
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, true, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, false, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, true, T>, b)) != hipSuccess) return e;
+    if constexpr (WavePrivate<Cfg>::value) {
+        if ((e = allow_lds(k_rowpair<RL_CFG_L, Q, ROW_FWD, T>, b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T>, b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T>, b)) != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
@@ -480,7 +514,8 @@ const KernelTable* RL_TABLE_FN() {
                                   {OuterTw<RL_CFG_L, OUTER>::fill, fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,
                                   WavePrivate<CCfg>::value ? launch_col_stream : nullptr,
                                   WavePrivate<Cfg>::value ? launch_row_stream : nullptr,
-                                  (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) ? launch_fused : nullptr};
+                                  (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) ? launch_fused : nullptr,
+                                  WavePrivate<Cfg>::value ? launch_row_pair : nullptr};
     return &t;
 }
 

@@ -43,6 +43,10 @@ struct KernelTable {
     // occupancy query allows); acquire: 1 = plain loads behind buffer_inv sc1, 0 = sc1 loads.
     // nullptr when the length has none.
     hipError_t (*launch_fused)(const void* params, int wgs_per_cu, int acquire, hipStream_t s, int* grid_out);
+    // Frame-pair row kernels (conv_kernels.hpp rowpair_body: two frames in one complex image, spectra [ny][L]; modes
+    // ROW_FWD / ROW_RATIO / ROW_UPDATE, one view): grid (ceil(ny / Q), pairs), RowParams::frames = frames covered.
+    // nullptr when the length's row transform is not wave private.
+    hipError_t (*launch_row_pair)(int dtype, int mode, const void* params, unsigned grid_y_pairs, hipStream_t s);
 };
 
 const KernelTable* table_64();

@@ -125,6 +125,74 @@ struct rl_deconv {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_iter_ms = 0, last_sim_ms = 0;
 
+    // ---- frame pairs (conv_kernels.hpp rowpair_body; RLSTED_PAIR): two frames ride through one complex image, the
+    // Richardson-Lucy loop of a single-view plan then runs on spectra [pairs][ny][lx] -- no Hermitian packing /
+    // splitting around the row transforms.  The simulation and the H / H_t calls keep the per-frame layout.
+    bool pair = false;
+    void *psf_hat_pair = nullptr, *psf_hat_pair_re = nullptr;   // psf_hat at full width: [lx][ly] (transposed layout)
+    void* spec_ones_pair = nullptr;                              // column-transformed spectrum of a pair of ones frames
+    size_t n_spec_pair() const { return spec_image_elems(ny, lx); }
+    void* pair_spec(int f0) const { return (char*)spec_a + (size_t)(f0 / 2) * n_spec_pair() * 2 * esize(dtype); }
+    template <typename T>
+    int col_pair_t(void* io, int pairs, bool h_mode) {
+        ColParams<T> p;
+        p.in = (const cx<T>*)io;
+        p.out = (cx<T>*)io;
+        p.psf_hat = (const cx<T>*)psf_hat_pair;
+        p.psf_hat_re = (const T*)psf_hat_pair_re;
+        p.qscale = h_mode ? q_est : q_ratio;
+        p.tw = (const cx<T>*)twy;
+        p.ny = ny; p.kx = lx; p.pitch = lx; p.V = 1;
+        p.mode = COL_PER_IMAGE; p.in_sb = 1; p.in_sv = 0;
+        p.images = pairs; p.order = col_order;
+        const int C = ty->C[dtype];
+        TimedScope t(this, h_mode ? TK_COL_H : TK_COL_HT);
+        HIP_TRY(ty->launch_col(dtype, &p, (unsigned)((lx + C - 1) / C), (unsigned)pairs, cur()));
+        return RL_OK;
+    }
+    int col_pair(void* io, int pairs, bool h_mode) {
+        const size_t sp = n_spec_pair() * 2 * esize(dtype);
+        for (int p0 = 0; p0 < pairs; p0 += kMaxGridY) {
+            const int np = std::min((int)kMaxGridY, pairs - p0);
+            RL_TRY(dtype == RL_F32 ? col_pair_t<float>((char*)io + (size_t)p0 * sp, np, h_mode)
+                                   : col_pair_t<double>((char*)io + (size_t)p0 * sp, np, h_mode));
+        }
+        return RL_OK;
+    }
+    // frames: images covered (even, or the batch's last odd one); spectra and images start at the launch's first pair
+    template <typename T>
+    int row_pair_t(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod) {
+        RowParams<T> p;
+        p.in_mod = in_mod;
+        p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
+        p.spec_in = (const cx<T>*)spec_in;
+        p.spec_out = (cx<T>*)spec_out;
+        p.src = (const T*)src;
+        p.dst = (T*)dst;
+        p.norm = (const T*)nrm;
+        p.scale = nullptr;
+        p.tw = (const cx<T>*)twx;
+        p.ny = ny; p.nx = nx; p.pitch = lx; p.V = 1;
+        p.frames = frames;
+        TimedScope t(this, mode == ROW_RATIO ? TK_RATIO : mode == ROW_UPDATE ? TK_UPDATE : TK_FWD);
+        HIP_TRY(tx->launch_row_pair(dtype, mode, &p, (unsigned)((frames + 1) / 2), cur()));
+        return RL_OK;
+    }
+    int row_pair(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod = 0) {
+        const size_t sp = n_spec_pair() * 2 * esize(dtype), im = n_img() * esize(dtype);
+        const int step = 2 * (int)kMaxGridY;
+        for (int f0 = 0; f0 < frames; f0 += step) {
+            const int nf = std::min(step, frames - f0);
+            const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)(f0 / 2) * sp) : nullptr;
+            void* so = (char*)spec_out + (size_t)(f0 / 2) * sp;
+            const void* sr = src ? (const char*)src + (size_t)f0 * im : nullptr;
+            void* ds = dst ? (char*)dst + (size_t)f0 * im : nullptr;
+            RL_TRY(dtype == RL_F32 ? row_pair_t<float>(mode, nf, si, so, sr, ds, nrm, in_mod)
+                                   : row_pair_t<double>(mode, nf, si, so, sr, ds, nrm, in_mod));
+        }
+        return RL_OK;
+    }
+
     // ---- separable strategy (sep_kernels.hip): every view rank 1 (p = u v^T) and small -> direct row + column stencils
     // instead of the FFT path.  RLSTED_SEP: 0 never, 1 (default) when py + px <= RLSTED_SEP_MAX_TAPS (16: the measured
     // crossover, profiles/r02/separable_vs_fft.json -- the FFT path's cost does not depend on the PSF size), 2 whenever rank 1.
@@ -491,13 +559,16 @@ struct rl_deconv {
         const int slices = (B + c - 1) / c;
         c = (B + slices - 1) / slices;
         if (c > 8) c = (c + 7) / 8 * 8;
-        return c;
+        if (pair && (c & 1)) ++c;   // slices of whole frame pairs
+        return c >= B ? B : c;
     }
     // estimate = 1 (ref:522).  with_spectrum: also spec_a = rowFFT(estimate); the first iteration does not need
     // it when it takes H(1) from spec_ones (iterate_chunk(first = true)).
     int start_estimate_chunk(int f0, int nf, bool with_spectrum = true) {
         HIP_TRY(aux_fill(dtype, off(est, (size_t)f0 * n_img()), (size_t)nf * n_img(), 1.0, cur()));
-        if (with_spectrum && !sep)
+        if (with_spectrum && pair)
+            RL_TRY(row_pair(ROW_FWD, nf, nullptr, pair_spec(f0), off(est, (size_t)f0 * n_img()), nullptr, nullptr));
+        else if (with_spectrum && !sep)
             RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, off(spec_a, (size_t)f0 * n_spec() * 2), off(est, (size_t)f0 * n_img()),
                        nullptr, nullptr));
         return RL_OK;
@@ -522,6 +593,19 @@ struct rl_deconv {
         } scale_guard{q_ratio, q_ratio};
         if (from_ones) q_ratio = q_est;
         if (sep) return sep_iterate(f0, nf);
+        if (pair) {   // the whole iteration in the pair spectra, in place
+            void* sp = pair_spec(f0);
+            const int np = (nf + 1) / 2;
+            if (first) {
+                RL_TRY(row_pair(ROW_RATIO, nf, spec_ones_pair, sp, off(meas, (size_t)f0 * n_img()), nullptr, nullptr, 1));
+            } else {
+                RL_TRY(col_pair(sp, np, true));
+                RL_TRY(row_pair(ROW_RATIO, nf, sp, sp, off(meas, (size_t)f0 * n_img()), nullptr, nullptr));
+            }
+            RL_TRY(col_pair(sp, np, false));
+            RL_TRY(row_pair(ROW_UPDATE, nf, sp, sp, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            return RL_OK;
+        }
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         if (first && V == 1 && inplace) {
@@ -576,8 +660,10 @@ struct rl_deconv {
             RL_TRY(sep_rows_(off(obj, (size_t)f0 * n_img()), off(sep_tmp(), o), nf * V, V));
             return sep_cols_(SEP_STORE_, off(sep_tmp(), o), nullptr, nullptr, off(noiseless, o), nf * V);
         }
-        void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
+        // (frame pairs: the other lane's slice iterates in spec_a in the pair layout, whose slice boundaries are not
+        // this layout's -- the simulation then stays in spec_b, in place)
+        void* sa = pair ? sb : off(spec_a, (size_t)f0 * n_spec() * 2);
         RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, sa, off(obj, (size_t)f0 * n_img()), nullptr, nullptr));
         RL_TRY(col(sa, sb, nf, true));
         RL_TRY(row(ROW_INV, (unsigned)(nf * V), sb, nullptr, nullptr, off(noiseless, (size_t)f0 * V * n_img()), nullptr));
@@ -598,7 +684,7 @@ struct rl_deconv {
     // (optionally restart from est = 1 and) run k iterations, slice by slice
     int run_iterations(int k, bool restart) { return run_slices(k, restart, false, 0, 0); }
     int run_slices(int k, bool restart, bool simulate, int rng_kind, uint64_t seed) {
-        const bool use_fused = fused_available() && k > 0 && !sep;
+        const bool use_fused = fused_available() && k > 0 && !sep && !pair;
         const int cf = chunk_frames();
         const int slices = (B + cf - 1) / cf;
         const int nl = slices < lanes ? slices : lanes;
@@ -782,7 +868,7 @@ int rl_deconv_destroy(rl_deconv* h) {
         hipStreamDestroy(h->sim_stream);
     }
     for (hipEvent_t ev : h->sim_done) hipEventDestroy(ev);
-    void* bufs[] = {h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
+    void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -975,6 +1061,50 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
     }
+    // ---- frame pairs for the Richardson-Lucy loop (single view, even batch, wave-private lengths) ----
+    // Default: f32 plans (the throughput mode).  f64 plans keep every frame's arithmetic independent of its neighbour in the
+    // batch (a pair's two frames share rounding errors: 1e-16-level differences with the partner frame).
+    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32);
+    if (want_pair && !h->sep && V == 1 && h->inplace && h->B % 2 == 0 && h->tx->launch_row_pair && h->psf_transposed()) {
+        const size_t nz = (size_t)h->lx * h->ly;
+        void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
+        RL_TRY(ctx->plain_twiddles(h->ly, &wy));
+        RL_TRY(ctx->plain_twiddles(h->lx, &wx));
+        HIP_TRY(hipMalloc(&h->psf_hat_pair, nz * 2 * es + RL_STREAM_SLACK));
+        HIP_TRY(hipMalloc(&psf_dev, (size_t)h->py * h->px * 8));
+        HIP_TRY(hipMalloc(&s1, (size_t)h->py * h->lx * 16));
+        HIP_TRY(hipMemcpyAsync(psf_dev, psfs, (size_t)h->py * h->px * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat_pair, 1, h->py, h->px, h->ly, h->lx,
+                                        h->lx, h->lx, 1, ctx->stream);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(psf_dev);
+        (void)hipFree(s1);
+        HIP_TRY(e);
+        HIP_TRY(e2);
+        h->bytes += nz * 2 * es + RL_STREAM_SLACK;
+        if (h->psf_hat_re) {   // the half-width spectrum is real: so is the full one
+            double* stats = nullptr;
+            HIP_TRY(hipMalloc(&h->psf_hat_pair_re, nz * es + RL_STREAM_SLACK));
+            HIP_TRY(hipMalloc((void**)&stats, 2 * sizeof(double)));
+            e = aux_split_real(h->dtype, h->psf_hat_pair, nz, h->psf_hat_pair_re, stats, ctx->stream);
+            e2 = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(stats);
+            HIP_TRY(e);
+            HIP_TRY(e2);
+            h->bytes += nz * es + RL_STREAM_SLACK;
+        }
+        h->pair = true;
+        // H(1 + i) of a pair of ones frames, column part: what every pair's first iteration reads
+        const size_t ones_bytes = h->n_spec_pair() * 2 * es;
+        HIP_TRY(hipMalloc(&h->spec_ones_pair, ones_bytes + RL_STREAM_SLACK));
+        HIP_TRY(aux_fill(h->dtype, h->est, 2 * h->n_img(), 1.0, ctx->stream));
+        RL_TRY(h->row_pair(ROW_FWD, 2, nullptr, h->spec_a, h->est, nullptr, nullptr));
+        RL_TRY(h->col_pair(h->spec_a, 1, true));
+        HIP_TRY(hipMemcpyAsync(h->spec_ones_pair, h->spec_a, ones_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(h->spec_ones_pair) + ones_bytes, 0, RL_STREAM_SLACK, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        h->bytes += ones_bytes + RL_STREAM_SLACK;
+    }
     return RL_OK;
 }
 
@@ -1110,6 +1240,10 @@ int rl_deconv_iterate(rl_deconv* h, int k) {
     HIP_TRY(hipSetDevice(h->ctx->device));
     HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
     bool restart = !h->est_ready;
+    if (!restart && !h->spec_valid && h->pair) {
+        RL_TRY(h->row_pair(ROW_FWD, h->B, nullptr, h->spec_a, h->est, nullptr, nullptr));
+        h->spec_valid = true;
+    }
     if (!restart && !h->spec_valid && !h->sep) {   // H / H_t were called in between: rebuild rowFFT(est)
         RL_TRY(h->row(ROW_FWD, (unsigned)h->B, nullptr, h->spec_a, h->est, nullptr, nullptr));
         h->spec_valid = true;
@@ -1221,8 +1355,9 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
 }
 
 
-int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl) {
+int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl, int* frame_pairs) {
     if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
+    if (frame_pairs) *frame_pairs = h->pair ? 1 : 0;
     if (separable) *separable = h->sep ? 1 : 0;
     if (real_psf_spectrum) *real_psf_spectrum = h->psf_hat_re ? 1 : 0;
     if (fused_rl) *fused_rl = h->fused_available() ? 1 : 0;

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../rescan_line_sted_amd/csrc/conv_kernels.hpp"
@@ -221,6 +222,12 @@ int emu_row_f32(int L, int mode, const float* spec_in, float* spec_out, const fl
     DISPATCH_L(L, (row_t<LL, float>(mode, spec_in, spec_out, src, dst, norm, scale, ny, nx, pitch, V, gy)))
 }
 
+// rowpair_body (two frames in one complex image): spectra [pairs][ny][L]; frames = images covered by the launch
+int emu_row_pair_f64(int L, int mode, const double* spec_in, double* spec_out, const double* src, double* dst, const double* norm,
+                     int ny, int nx, int frames, int in_mod);
+int emu_row_pair_f32(int L, int mode, const float* spec_in, float* spec_out, const float* src, float* dst, const float* norm,
+                     int ny, int nx, int frames, int in_mod);
+
 // colconv_outer_body (long column transforms on a wave-private core): L = M * Li, Li in {256, 576}.
 // psf_hat: complex [V][kx][L] (transposed layout), or -- real_psf -- its real parts [V][kx][L].
 }  // extern "C"
@@ -263,7 +270,43 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
              });
     return 0;
 }
+template <int L, typename T>
+static int row_pair_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, int ny, int nx, int frames, int in_mod) {
+    using CF = CfgFor<L>;
+    using Cfg = typename CF::Cfg;
+    if constexpr (WavePrivate<Cfg>::value) {
+        constexpr int Q = sizeof(T) == 4 ? CF::Q32 : CF::Q64;
+        auto tw = twiddles<L, T>();
+        RowParams<T> p;
+        p.spec_in = reinterpret_cast<const cx<T>*>(spec_in);
+        p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
+        p.src = src; p.dst = dst; p.norm = norm; p.scale = nullptr; p.tw = tw.data();
+        p.ny = ny; p.nx = nx; p.pitch = L; p.V = 1; p.frames = frames; p.in_mod = in_mod;
+        auto run = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            run_grid((ny + Q - 1) / Q, (frames + 1) / 2, 64 * Q, (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>),
+                     [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                         rowpair_body<Cfg, Q, MODE, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                     });
+        };
+        if (mode == ROW_FWD) run(std::integral_constant<int, ROW_FWD>{});
+        else if (mode == ROW_RATIO) run(std::integral_constant<int, ROW_RATIO>{});
+        else if (mode == ROW_UPDATE) run(std::integral_constant<int, ROW_UPDATE>{});
+        else return -1;
+        return 0;
+    } else {
+        return -3;
+    }
+}
 extern "C" {
+int emu_row_pair_f64(int L, int mode, const double* spec_in, double* spec_out, const double* src, double* dst, const double* norm,
+                     int ny, int nx, int frames, int in_mod) {
+    DISPATCH_L(L, (row_pair_t<LL, double>(mode, spec_in, spec_out, src, dst, norm, ny, nx, frames, in_mod)))
+}
+int emu_row_pair_f32(int L, int mode, const float* spec_in, float* spec_out, const float* src, float* dst, const float* norm,
+                     int ny, int nx, int frames, int in_mod) {
+    DISPATCH_L(L, (row_pair_t<LL, float>(mode, spec_in, spec_out, src, dst, norm, ny, nx, frames, in_mod)))
+}
 int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
                       int pitch, int V, int frames, int in_sb, int in_sv) {
     using C256 = CfgFor<256>::Cfg;

@@ -417,3 +417,51 @@ def test_outer_decimation_multi_view_modes(emu, Li, mode, ny, kx, real_psf):
         else:
             ref = np.fft.ifft(sum(spec[f * V + v] * ph[v].T for v in range(V)), axis=0)[:ny] * L
             assert max_rel(out[f][:, :kx], ref) < 1e-12, f
+
+
+# ------------------------------------------------- frame pairs: two frames in one complex image
+@pytest.mark.parametrize('L,ny,nx,frames,sfx', [(576, 5, 512, 4, 'f64'), (576, 3, 301, 3, 'f64'), (256, 6, 200, 2, 'f64'),
+                                                 (576, 2, 512, 2, 'f32'), (256, 3, 97, 5, 'f32')])
+def test_frame_pair_row_kernels(emu, L, ny, nx, frames, sfx):
+    """rowpair_body: frames 2p / 2p+1 are the real / imaginary part of one complex row transform; the spectrum of a pair
+    is [ny][L] complex.  ROW_FWD, ROW_RATIO and ROW_UPDATE against numpy (unnormalised transforms both ways, like
+    the per-frame kernels); an odd frame count leaves the last pair's imaginary part empty."""
+    rt = np.float64 if sfx == 'f64' else np.float32
+    ct = np.complex128 if sfx == 'f64' else np.complex64
+    tol = 1e-12 if sfx == 'f64' else 3e-5
+    rng = np.random.default_rng(L + ny + nx)
+    pairs = (frames + 1) // 2
+    f = getattr(emu, 'emu_row_pair_' + sfx)
+
+    def padded(a):               # (frames, ny, nx) real -> (pairs, ny, L) complex
+        z = np.zeros((pairs, ny, L), dtype=np.complex128)
+        for i in range(frames):
+            if i % 2 == 0:
+                z[i // 2, :, :nx] += a[i]
+            else:
+                z[i // 2, :, :nx] += 1j * a[i]
+        return z
+
+    est = _slack((rng.random((frames, ny, nx)) + 0.5).astype(rt))
+    spec = _slack(np.full((pairs, ny, L), np.nan + 1j * np.nan, dtype=ct))
+    assert f(L, ROW_FWD, None, _p(spec), _p(est), None, None, ny, nx, frames, 0) == 0
+    ref = np.fft.fft(padded(est.astype(np.float64)), axis=2)
+    assert max_rel(spec, ref) < tol
+    # ROW_RATIO: the spectrum of positive rows (H(estimate) > 0), ratio = measurement / z
+    zpos = rng.random((frames, ny, nx)) * 3 + 0.2
+    s_pos = _slack((np.fft.fft(padded(zpos), axis=2) / L).astype(ct))
+    meas = _slack((rng.random((frames, ny, nx)) * 5 + 1).astype(rt))
+    out = _slack(np.full((pairs, ny, L), np.nan + 1j * np.nan, dtype=ct))
+    assert f(L, ROW_RATIO, _p(s_pos), _p(out), _p(meas), None, None, ny, nx, frames, 0) == 0
+    assert max_rel(out, np.fft.fft(padded(meas.astype(np.float64) / zpos), axis=2)) < (1e-11 if sfx == 'f64' else 3e-5)
+    # ROW_UPDATE on an arbitrary spectrum whose inverse has both signs (the clamp matters):
+    # est *= max(z, 0) / norm, spectrum of the new estimate
+    s_in = _slack((rng.standard_normal((pairs, ny, L)) + 1j * rng.standard_normal((pairs, ny, L))).astype(ct))
+    z = np.fft.ifft(s_in.astype(np.complex128), axis=2) * L
+    e = np.stack([(z[i // 2].real if i % 2 == 0 else z[i // 2].imag)[:, :nx] for i in range(frames)])
+    norm = _slack((rng.random((ny, nx)) + 0.5).astype(rt))
+    est0 = est.astype(np.float64).copy()
+    assert f(L, ROW_UPDATE, _p(s_in), _p(out), None, _p(est), _p(norm), ny, nx, frames, 0) == 0
+    want = est0 * np.maximum(e, 0) / norm.astype(np.float64)
+    assert max_rel(est, want) < (1e-12 if sfx == 'f64' else 2e-6)
+    assert max_rel(out, np.fft.fft(padded(want), axis=2)) < tol

@@ -445,3 +445,64 @@ def test_edge_cases(lib):
     fresh = lib.DeconvPlan([rng.random((1, 5, 5))], 1, 16, 16)
     with pytest.raises(lib.RlstedError):
         fresh.iterate(1)                                                          # no measurement yet
+
+
+# ------------------------------------- frame pairs (two frames in one complex image) in the RL loop
+@pytest.mark.parametrize('ny,nx,B', [(30, 41, 2), (128, 128, 4), (190, 203, 6), (245, 140, 2), (511, 300, 2), (200, 500, 4)])
+def test_frame_pair_loop_equals_per_frame_loop(lib, ny, nx, B, monkeypatch):
+    """RLSTED_PAIR=1 (default for single-view plans with an even batch on the wave-private lengths 64 ... 576): the RL
+    loop transforms frames 2p and 2p+1 as the real and imaginary part of one complex image.  Same estimates as the
+    per-frame loop (f64: rounding level), also across set_estimate / forward calls that invalidate the spectra."""
+    rng = np.random.default_rng(ny + nx)
+    psf = [(rng.random((1, 9, 12)) + 0.02)]
+    x = rng.random((B, ny, nx)) * 40
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RLSTED_PAIR', flag)
+        plan = lib.DeconvPlan(psf, B, ny, nx, dtype='f64')
+        info = plan.info()                   # pairs exist where both transforms are one-per-wave: L = 256, 576
+        assert plan.strategy()['frame_pairs'] == (flag == '1' and info['ly'] in (256, 576) and info['lx'] in (256, 576))
+        plan.set_object(x, 1e7)
+        plan.simulate(seed=3)
+        plan.iterate(3)
+        a = plan.estimate()
+        plan.forward(x)                      # clobbers the spectra: the next iterate rebuilds them from the estimate
+        plan.iterate(2)
+        b = plan.estimate()
+        plan.set_estimate(b * 1.5)
+        plan.iterate(1)
+        out[flag] = (a, b, plan.estimate(), plan.measurement())
+    assert np.array_equal(out['1'][3], out['0'][3])
+    for i in range(3):
+        assert max_rel(out['1'][i], out['0'][i]) < 1e-12, i
+    d = orc.Deconvolver(psf)
+    d.create_data_from_object(x[:1], noisy_measurement=[out['1'][3][:1, 0]])
+    for _ in range(3):
+        d.iterate()
+    assert max_rel(out['1'][0][0], d.estimate[0]) < 1e-11
+
+
+def test_frame_pair_loop_f32_within_contract(lib, golden, astronaut512, monkeypatch):
+    """f32: the pair loop is as accurate as the per-frame loop (same transforms, the packing / splitting arithmetic
+    gone): inside the contract on the BASELINE object; on white noise f32 sits at 0.8 ... 1.0e-5 after 20 iterations
+    either way (frame by frame the two loops differ by +-20 %, on average by nothing)."""
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    noise = np.random.default_rng(5).random((2, 512, 512)) * 200
+    objs = np.concatenate([astronaut512, astronaut512.transpose(0, 2, 1), noise])
+    monkeypatch.setenv('RLSTED_PAIR', '0')
+    ref = lib.DeconvPlan(psf, 4, 512, 512, dtype='f64')
+    ref.set_object(objs, 8e11)
+    ref.simulate(seed=11)
+    noisy = ref.measurement()
+    ref.iterate(20)
+    err = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RLSTED_PAIR', flag)
+        plan = lib.DeconvPlan(psf, 4, 512, 512, dtype='f32')
+        plan.set_object(objs, 8e11)
+        plan.set_measurement(noisy)
+        plan.iterate(20)
+        err[flag] = [max_rel(plan.estimate()[f], ref.estimate()[f]) for f in range(4)]
+        assert max(err[flag][:2]) < F32_TOL, (flag, err[flag])
+    assert max(err['1'] + err['0']) < 1.1e-5, err                       # white noise: at the edge of the contract either way
+    assert np.mean(err['1']) < 1.1 * np.mean(err['0']), err

@@ -20,6 +20,7 @@ import sys
 from collections import defaultdict
 
 NAMES = (  # (regex on the kernel name, key in the json); first match wins
+    (r'k_rowpair<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpair<\d+, \d+, 3,', 'rowpass_UPDATE'), (r'k_rowpair<\d+, \d+, 0,', 'rowpair_FWD'),
     (r'k_rowpass<\d+, \d+, 0,', 'rowpass_FWD'), (r'k_rowpass<\d+, \d+, 1,', 'rowpass_INV'),
     (r'k_rowpass<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpass<\d+, \d+, 3,', 'rowpass_UPDATE'),
     (r'k_rowpass<\d+, \d+, 4,', 'rowpass_ADJ'), (r'k_rowstream<\d+, \d+, 2,', 'rowstream_RATIO'),
