@@ -1178,7 +1178,8 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 //   ROW_UPDATE  z = rowIFFT(spec_in); est_a *= max(Re z, 0) / norm, est_b *= max(Im z, 0) / norm; spec_out = rowFFT(est)
 // The spectrum row is loaded straight into the register layout the first inverse pass takes (the layout the last forward
 // pass leaves: that is what lets FFT -> pointwise -> IFFT chain in the column kernel) and stored from it.
-// Single view, wave-private lengths; an odd frame count leaves the last pair's imaginary part empty.
+// Wave-private lengths; an odd frame count leaves the last pair's imaginary part empty.  Multi-view plans: ROW_RATIO runs
+// per (pair, view) image (p.V views), ROW_FWD / ROW_UPDATE on the pair's single (view-summed) spectrum with p.V = 1.
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "pair rows need wave-private transforms");
@@ -1198,8 +1199,10 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     if (row >= p.ny) return;   // whole wave; no workgroup barrier below
     LdsView<T, 1, LdsGather<L>::value> view_lds{lds + q * LP};
     const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
-    const bool okb = 2 * by + 1 < p.frames;
-    const size_t ra = ((size_t)(2 * by) * p.ny + row) * p.nx, rb = okb ? ra + rimg : ra;   // frame a / b, this row
+    // by = pair * V + view (ROW_RATIO of a multi-view plan: measurement images are [frame][view]); V = 1 otherwise
+    const int pr = by / p.V, vw = by % p.V;
+    const bool okb = 2 * pr + 1 < p.frames;
+    const size_t ra = ((size_t)(2 * pr * p.V + vw) * p.ny + row) * p.nx, rb = okb ? ra + (size_t)p.V * rimg : ra;   // frame a / b, this row
     const int tail_k = (64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF;
 
     // operands of the pointwise stage, requested ahead of the inverse transform

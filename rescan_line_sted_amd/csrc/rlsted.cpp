@@ -125,6 +125,7 @@ struct rl_deconv {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_iter_ms = 0, last_sim_ms = 0;
 
+    enum ColKind { COL_H, COL_HT_VIEW, COL_HT_FUSED };
     // ---- frame pairs (conv_kernels.hpp rowpair_body; RLSTED_PAIR): two frames ride through one complex image, the
     // Richardson-Lucy loop of a single-view plan then runs on spectra [pairs][ny][lx] -- no Hermitian packing /
     // splitting around the row transforms.  The simulation and the H / H_t calls keep the per-frame layout.
@@ -133,35 +134,41 @@ struct rl_deconv {
     void* spec_ones_pair = nullptr;                              // column-transformed spectrum of a pair of ones frames
     size_t n_spec_pair() const { return spec_image_elems(ny, lx); }
     void* pair_spec(int f0) const { return (char*)spec_a + (size_t)(f0 / 2) * n_spec_pair() * 2 * esize(dtype); }
+    // kind: COL_H (pair spectrum -> V images; in place when V == 1), COL_HT_VIEW (V == 1, in place) or COL_HT_FUSED
+    // (V images summed in the Fourier domain -> pair spectrum)
     template <typename T>
-    int col_pair_t(void* io, int pairs, bool h_mode) {
+    int col_pair_t(const void* in, void* out, int pairs, ColKind kind) {
         ColParams<T> p;
-        p.in = (const cx<T>*)io;
-        p.out = (cx<T>*)io;
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
         p.psf_hat = (const cx<T>*)psf_hat_pair;
         p.psf_hat_re = (const T*)psf_hat_pair_re;
-        p.qscale = h_mode ? q_est : q_ratio;
+        p.qscale = kind == COL_H ? q_est : q_ratio;
         p.tw = (const cx<T>*)twy;
-        p.ny = ny; p.kx = lx; p.pitch = lx; p.V = 1;
-        p.mode = COL_PER_IMAGE; p.in_sb = 1; p.in_sv = 0;
+        p.ny = ny; p.kx = lx; p.pitch = lx; p.V = V;
+        p.mode = V == 1 ? COL_PER_IMAGE : (kind == COL_H ? COL_H_MULTI : COL_HT_SUM);
+        p.in_sb = 1; p.in_sv = 0;
         p.images = pairs; p.order = col_order;
         const int C = ty->C[dtype];
-        TimedScope t(this, h_mode ? TK_COL_H : TK_COL_HT);
+        TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
         HIP_TRY(ty->launch_col(dtype, &p, (unsigned)((lx + C - 1) / C), (unsigned)pairs, cur()));
         return RL_OK;
     }
-    int col_pair(void* io, int pairs, bool h_mode) {
+    int col_pair(const void* in, void* out, int pairs, ColKind kind) {
         const size_t sp = n_spec_pair() * 2 * esize(dtype);
+        const size_t in_per = kind == COL_H ? 1 : (size_t)V, out_per = kind == COL_H ? (size_t)V : 1;
         for (int p0 = 0; p0 < pairs; p0 += kMaxGridY) {
             const int np = std::min((int)kMaxGridY, pairs - p0);
-            RL_TRY(dtype == RL_F32 ? col_pair_t<float>((char*)io + (size_t)p0 * sp, np, h_mode)
-                                   : col_pair_t<double>((char*)io + (size_t)p0 * sp, np, h_mode));
+            const void* i = (const char*)in + (size_t)p0 * in_per * sp;
+            void* o = (char*)out + (size_t)p0 * out_per * sp;
+            RL_TRY(dtype == RL_F32 ? col_pair_t<float>(i, o, np, kind) : col_pair_t<double>(i, o, np, kind));
         }
         return RL_OK;
     }
+    int col_pair(void* io, int pairs, bool h_mode) { return col_pair(io, io, pairs, h_mode ? COL_H : COL_HT_VIEW); }
     // frames: images covered (even, or the batch's last odd one); spectra and images start at the launch's first pair
     template <typename T>
-    int row_pair_t(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod) {
+    int row_pair_t(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod, int views) {
         RowParams<T> p;
         p.in_mod = in_mod;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
@@ -172,23 +179,25 @@ struct rl_deconv {
         p.norm = (const T*)nrm;
         p.scale = nullptr;
         p.tw = (const cx<T>*)twx;
-        p.ny = ny; p.nx = nx; p.pitch = lx; p.V = 1;
+        p.ny = ny; p.nx = nx; p.pitch = lx; p.V = views;
         p.frames = frames;
         TimedScope t(this, mode == ROW_RATIO ? TK_RATIO : mode == ROW_UPDATE ? TK_UPDATE : TK_FWD);
-        HIP_TRY(tx->launch_row_pair(dtype, mode, &p, (unsigned)((frames + 1) / 2), cur()));
+        HIP_TRY(tx->launch_row_pair(dtype, mode, &p, (unsigned)((frames + 1) / 2 * views), cur()));
         return RL_OK;
     }
-    int row_pair(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod = 0) {
+    // views > 1 (ROW_RATIO of a multi-view plan): one launch image per (pair, view); spectra [pair][view], images [frame][view]
+    int row_pair(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod = 0,
+                 int views = 1) {
         const size_t sp = n_spec_pair() * 2 * esize(dtype), im = n_img() * esize(dtype);
-        const int step = 2 * (int)kMaxGridY;
+        const int step = 2 * ((int)kMaxGridY / views);
         for (int f0 = 0; f0 < frames; f0 += step) {
             const int nf = std::min(step, frames - f0);
-            const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)(f0 / 2) * sp) : nullptr;
-            void* so = (char*)spec_out + (size_t)(f0 / 2) * sp;
-            const void* sr = src ? (const char*)src + (size_t)f0 * im : nullptr;
+            const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)(f0 / 2) * views * sp) : nullptr;
+            void* so = (char*)spec_out + (size_t)(f0 / 2) * views * sp;
+            const void* sr = src ? (const char*)src + (size_t)f0 * views * im : nullptr;
             void* ds = dst ? (char*)dst + (size_t)f0 * im : nullptr;
-            RL_TRY(dtype == RL_F32 ? row_pair_t<float>(mode, nf, si, so, sr, ds, nrm, in_mod)
-                                   : row_pair_t<double>(mode, nf, si, so, sr, ds, nrm, in_mod));
+            RL_TRY(dtype == RL_F32 ? row_pair_t<float>(mode, nf, si, so, sr, ds, nrm, in_mod, views)
+                                   : row_pair_t<double>(mode, nf, si, so, sr, ds, nrm, in_mod, views));
         }
         return RL_OK;
     }
@@ -368,7 +377,6 @@ struct rl_deconv {
     size_t n_img() const { return (size_t)ny * nx; }
     size_t n_spec() const { return spec_image_elems(ny, pitch); }   // complex elements of one spectrum image
 
-    enum ColKind { COL_H, COL_HT_VIEW, COL_HT_FUSED };
     bool wave_private_y() const { return ty->col_multi[dtype] != 0; }    // the multi-view column modes exist
     bool psf_transposed() const { return ty->psf_transposed[dtype] != 0; }   // psf_hat is [view][Kx][Ly]
     template <typename T>
@@ -593,6 +601,21 @@ struct rl_deconv {
         } scale_guard{q_ratio, q_ratio};
         if (from_ones) q_ratio = q_est;
         if (sep) return sep_iterate(f0, nf);
+        if (pair && V > 1) {   // est pair spectra in spec_a, the V view images of every pair in spec_b, views summed in the column pass
+            void* sa = pair_spec(f0);
+            void* sb = (char*)spec_b + (size_t)(f0 / 2) * V * n_spec_pair() * 2 * esize(dtype);
+            const int np = (nf + 1) / 2;
+            const void* m = off(meas, (size_t)f0 * V * n_img());
+            if (first) {
+                RL_TRY(row_pair(ROW_RATIO, nf, spec_ones_pair, sb, m, nullptr, nullptr, V, V));
+            } else {
+                RL_TRY(col_pair(sa, sb, np, COL_H));
+                RL_TRY(row_pair(ROW_RATIO, nf, sb, sb, m, nullptr, nullptr, 0, V));
+            }
+            RL_TRY(col_pair(sb, sa, np, COL_HT_FUSED));
+            RL_TRY(row_pair(ROW_UPDATE, nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            return RL_OK;
+        }
         if (pair) {   // the whole iteration in the pair spectra, in place
             void* sp = pair_spec(f0);
             const int np = (nf + 1) / 2;
@@ -663,7 +686,8 @@ struct rl_deconv {
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         // (frame pairs: the other lane's slice iterates in spec_a in the pair layout, whose slice boundaries are not
         // this layout's -- the simulation then stays in spec_b, in place)
-        void* sa = pair ? sb : off(spec_a, (size_t)f0 * n_spec() * 2);
+        // (V > 1: the frame spectra go through scratch, which is idle during run_slices and large enough -- deconv_build checks)
+        void* sa = !pair ? off(spec_a, (size_t)f0 * n_spec() * 2) : V == 1 ? sb : off(scratch, (size_t)f0 * V * n_img());
         RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, sa, off(obj, (size_t)f0 * n_img()), nullptr, nullptr));
         RL_TRY(col(sa, sb, nf, true));
         RL_TRY(row(ROW_INV, (unsigned)(nf * V), sb, nullptr, nullptr, off(noiseless, (size_t)f0 * V * n_img()), nullptr));
@@ -1064,17 +1088,21 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     // ---- frame pairs for the Richardson-Lucy loop (single view, even batch, wave-private lengths) ----
     // Default: f32 plans (the throughput mode).  f64 plans keep every frame's arithmetic independent of its neighbour in the
     // batch (a pair's two frames share rounding errors: 1e-16-level differences with the partner frame).
-    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32);
-    if (want_pair && !h->sep && V == 1 && h->inplace && h->B % 2 == 0 && h->tx->launch_row_pair && h->psf_transposed()) {
-        const size_t nz = (size_t)h->lx * h->ly;
+    // Multi-view plans: built and tested (RLSTED_PAIR=1), no gain (512^2, 4 views: 30.0 ms per 64 frames x 20 iterations either
+    // way -- the multi-view column kernels set the pace), so the default pairs single-view plans only.
+    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32 && V == 1);
+    const bool pair_views_ok = V == 1 ? h->inplace
+                                      : (h->fuse_views && h->wave_private_y() && h->n_spec() * 2 <= V * h->n_img());   // (frame spectra fit scratch)
+    if (want_pair && !h->sep && pair_views_ok && h->B % 2 == 0 && h->tx->launch_row_pair && h->psf_transposed()) {
+        const size_t nz = V * (size_t)h->lx * h->ly;
         void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
         RL_TRY(ctx->plain_twiddles(h->ly, &wy));
         RL_TRY(ctx->plain_twiddles(h->lx, &wx));
         HIP_TRY(hipMalloc(&h->psf_hat_pair, nz * 2 * es + RL_STREAM_SLACK));
-        HIP_TRY(hipMalloc(&psf_dev, (size_t)h->py * h->px * 8));
-        HIP_TRY(hipMalloc(&s1, (size_t)h->py * h->lx * 16));
-        HIP_TRY(hipMemcpyAsync(psf_dev, psfs, (size_t)h->py * h->px * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat_pair, 1, h->py, h->px, h->ly, h->lx,
+        HIP_TRY(hipMalloc(&psf_dev, V * (size_t)h->py * h->px * 8));
+        HIP_TRY(hipMalloc(&s1, V * (size_t)h->py * h->lx * 16));
+        HIP_TRY(hipMemcpyAsync(psf_dev, psfs, V * (size_t)h->py * h->px * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat_pair, h->V, h->py, h->px, h->ly, h->lx,
                                         h->lx, h->lx, 1, ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
         (void)hipFree(psf_dev);
@@ -1082,7 +1110,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         HIP_TRY(e);
         HIP_TRY(e2);
         h->bytes += nz * 2 * es + RL_STREAM_SLACK;
-        if (h->psf_hat_re) {   // the half-width spectrum is real: so is the full one
+        if (h->psf_hat_re) {   // the half-width spectra are real: so are the full ones
             double* stats = nullptr;
             HIP_TRY(hipMalloc(&h->psf_hat_pair_re, nz * es + RL_STREAM_SLACK));
             HIP_TRY(hipMalloc((void**)&stats, 2 * sizeof(double)));
@@ -1094,13 +1122,13 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
             h->bytes += nz * es + RL_STREAM_SLACK;
         }
         h->pair = true;
-        // H(1 + i) of a pair of ones frames, column part: what every pair's first iteration reads
-        const size_t ones_bytes = h->n_spec_pair() * 2 * es;
+        // H(1 + i) of a pair of ones frames, column part (one spectrum per view): what every pair's first iteration reads
+        const size_t ones_bytes = V * h->n_spec_pair() * 2 * es;
         HIP_TRY(hipMalloc(&h->spec_ones_pair, ones_bytes + RL_STREAM_SLACK));
         HIP_TRY(aux_fill(h->dtype, h->est, 2 * h->n_img(), 1.0, ctx->stream));
         RL_TRY(h->row_pair(ROW_FWD, 2, nullptr, h->spec_a, h->est, nullptr, nullptr));
-        RL_TRY(h->col_pair(h->spec_a, 1, true));
-        HIP_TRY(hipMemcpyAsync(h->spec_ones_pair, h->spec_a, ones_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        RL_TRY(h->col_pair(h->spec_a, V == 1 ? h->spec_a : h->spec_b, 1, rl_deconv::COL_H));
+        HIP_TRY(hipMemcpyAsync(h->spec_ones_pair, V == 1 ? h->spec_a : h->spec_b, ones_bytes, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(hipMemsetAsync(static_cast<char*>(h->spec_ones_pair) + ones_bytes, 0, RL_STREAM_SLACK, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         h->bytes += ones_bytes + RL_STREAM_SLACK;

@@ -506,3 +506,27 @@ def test_frame_pair_loop_f32_within_contract(lib, golden, astronaut512, monkeypa
         assert max(err[flag][:2]) < F32_TOL, (flag, err[flag])
     assert max(err['1'] + err['0']) < 1.1e-5, err                       # white noise: at the edge of the contract either way
     assert np.mean(err['1']) < 1.1 * np.mean(err['0']), err
+
+
+@pytest.mark.parametrize('ny,nx,B,V', [(190, 203, 4, 3), (511, 300, 2, 2), (512, 512, 6, 4)])
+def test_frame_pair_loop_multi_view(lib, ny, nx, B, V, monkeypatch):
+    """Frame pairs in a multi-view plan (views summed in the column pass, RLSTED_FUSE_VIEWS: the f32 default): the V view
+    images of a pair are complex images too; same estimates as the per-frame loop with the same view fusion."""
+    rng = np.random.default_rng(ny + V)
+    psfs = [(rng.random((1, 9, 12)) + 0.02) for _ in range(V)]
+    x = rng.random((B, ny, nx)) * 40
+    monkeypatch.setenv('RLSTED_FUSE_VIEWS', '1')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RLSTED_PAIR', flag)
+        plan = lib.DeconvPlan(psfs, B, ny, nx, dtype='f64')
+        assert plan.strategy()['frame_pairs'] == (flag == '1')
+        plan.set_object(x, 1e7)
+        plan.simulate(seed=3)
+        plan.iterate(4)
+        a = plan.estimate()
+        plan.adjoint(rng.random((B, V, ny, nx)))          # clobbers the spectra
+        plan.iterate(2)
+        out[flag] = (a, plan.estimate(), plan.measurement(), plan.noiseless())
+    assert np.array_equal(out['1'][2], out['0'][2]) and np.array_equal(out['1'][3], out['0'][3])
+    assert max_rel(out['1'][0], out['0'][0]) < 1e-12 and max_rel(out['1'][1], out['0'][1]) < 1e-12
