@@ -1180,6 +1180,9 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 // pass leaves: that is what lets FFT -> pointwise -> IFFT chain in the column kernel) and stored from it.
 // Wave-private lengths; an odd frame count leaves the last pair's imaginary part empty.  Multi-view plans: ROW_RATIO runs
 // per (pair, view) image (p.V views), ROW_FWD / ROW_UPDATE on the pair's single (view-summed) spectrum with p.V = 1.
+#ifndef RL_PAIR_NRM_EARLY
+#define RL_PAIR_NRM_EARLY 1
+#endif
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "pair rows need wave-private transforms");
@@ -1205,12 +1208,13 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     const size_t ra = ((size_t)(2 * pr * p.V + vw) * p.ny + row) * p.nx, rb = okb ? ra + (size_t)p.V * rimg : ra;   // frame a / b, this row
     const int tail_k = (64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF;
 
-    // operands of the pointwise stage, requested ahead of the inverse transform
-    cx<T> pre[NB * R], nrm[MODE == ROW_UPDATE ? NB * R : 1];
+    // operands of the pointwise stage: measurement / estimate requested ahead of the inverse transform, the normaliser
+    // (an L2 hit: one image shared by all frames) ahead of it too or right behind it (RL_PAIR_NRM_EARLY: registers against waits)
+    cx<T> pre[NB * R];
+    T nrm[MODE == ROW_UPDATE ? NB * R : 1];
     {
         const T* __restrict__ s0 = (MODE == ROW_UPDATE ? p.dst : p.src) + ra;
         const T* __restrict__ s1 = (MODE == ROW_UPDATE ? p.dst : p.src) + rb;
-        const T* __restrict__ n0 = p.norm + (size_t)row * p.nx;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1218,9 +1222,21 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 const int i = (t + nb * 64) + r * NBF;
                 const bool inx = (t + nb * 64) < NBF && i < p.nx;
                 pre[nb * R + r] = inx ? mk<T>(s0[i], s1[i]) : mk<T>((T)0, (T)0);
-                if constexpr (MODE == ROW_UPDATE) nrm[nb * R + r] = inx ? mk<T>(n0[i], n0[i]) : mk<T>((T)1, (T)1);
             }
     }
+    auto request_norm = [&] {
+        if constexpr (MODE == ROW_UPDATE) {
+            const T* __restrict__ n0 = p.norm + (size_t)row * p.nx;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = (t + nb * 64) + r * NBF;
+                    nrm[nb * R + r] = ((t + nb * 64) < NBF && i < p.nx) ? n0[i] : (T)1;
+                }
+        }
+    };
+    if constexpr (RL_PAIR_NRM_EARLY != 0) request_norm();
     cx<T> v[VMAX];
     cx<T> tl = mk<T>((T)0, (T)0);
     if constexpr (MODE != ROW_FWD) {
@@ -1235,6 +1251,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         if constexpr (I0::TAIL) tl = rl_ldg(sync, si + tail_k);
         run_passes<Cfg, true, 0, true>(v, tl, t, view_lds, p.tw, sync);
     }
+    if constexpr (RL_PAIR_NRM_EARLY == 0) request_norm();
 #pragma unroll
     for (int s = 0; s < NB * R; ++s) {
         const int nb = s / R, r = s % R;
@@ -1249,8 +1266,8 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
                 z.im = inx && okb ? rl_div(pre[s].im, e1) : (T)0;
             } else {
-                z.re = inx ? pre[s].re * rl_div(e0, nrm[s].re) : (T)0;
-                z.im = inx && okb ? pre[s].im * rl_div(e1, nrm[s].im) : (T)0;
+                z.re = inx ? pre[s].re * rl_div(e0, nrm[s]) : (T)0;
+                z.im = inx && okb ? pre[s].im * rl_div(e1, nrm[s]) : (T)0;
                 if (inx) p.dst[ra + i] = z.re;
                 if (inx && okb) p.dst[rb + i] = z.im;
             }

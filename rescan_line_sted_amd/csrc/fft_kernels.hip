@@ -435,8 +435,14 @@ static hipError_t launch_row(int dtype, int mode, const void* params, unsigned g
     return dtype == DT_F32 ? launch_row_t<kQ32, float>(mode, params, gx, gy, s)
                            : launch_row_t<kQ64, double>(mode, params, gx, gy, s);
 }
+// rows (= waves) per workgroup of the frame-pair row kernels, f32 (RL_PAIR_Q32; measured at 512^2: 2 / 4 / 8 / 16 rows
+// 18.4 / 18.8 / 19.1 / ... k frames/s)
+#ifndef RL_PAIR_Q32
+#define RL_PAIR_Q32 8
+#endif
+constexpr int kPairQ32 = WavePrivate<Cfg>::value ? RL_PAIR_Q32 : kQ32;
 static hipError_t launch_row_pair(int dtype, int mode, const void* params, unsigned gy, hipStream_t s) {
-    return dtype == DT_F32 ? launch_row_pair_t<kQ32, float>(mode, params, gy, s)
+    return dtype == DT_F32 ? launch_row_pair_t<kPairQ32, float>(mode, params, gy, s)
                            : launch_row_pair_t<kQ64, double>(mode, params, gy, s);
 }
 
@@ -458,9 +464,11 @@ static hipError_t prepare_rows() {
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, false, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, true, T>, b)) != hipSuccess) return e;
     if constexpr (WavePrivate<Cfg>::value) {
-        if ((e = allow_lds(k_rowpair<RL_CFG_L, Q, ROW_FWD, T>, b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T>, b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T>, b)) != hipSuccess) return e;
+        constexpr int QP = sizeof(T) == 4 ? kPairQ32 : Q;
+        const size_t bp = lds_bytes<QP, T>();
+        if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_FWD, T>, bp)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_RATIO, T>, bp)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_UPDATE, T>, bp)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
