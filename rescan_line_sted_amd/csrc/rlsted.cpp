@@ -1093,7 +1093,8 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32 && V == 1);
     const bool pair_views_ok = V == 1 ? h->inplace
                                       : (h->fuse_views && h->wave_private_y() && h->n_spec() * 2 <= V * h->n_img());   // (frame spectra fit scratch)
-    if (want_pair && !h->sep && pair_views_ok && h->B % 2 == 0 && h->tx->launch_row_pair && h->psf_transposed()) {
+    // (an explicitly requested fused kernel or streaming flavour keeps the per-frame layout they are written for)
+    if (want_pair && !h->sep && !h->fused && h->streaming == 0 && pair_views_ok && h->B % 2 == 0 && h->tx->launch_row_pair && h->psf_transposed()) {
         const size_t nz = V * (size_t)h->lx * h->ly;
         void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
         RL_TRY(ctx->plain_twiddles(h->ly, &wy));

@@ -91,9 +91,11 @@ def test_fused_rl_kernel_matches_the_four_launch_iteration(lib, golden, monkeypa
     obj = np.kron(golden('objects')['astronaut'].astype(np.float64), np.ones((1, 4, 4)))[0]
     B = 24
     est = {}
+    monkeypatch.setenv('RLSTED_PAIR', '0')      # like with like: the fused kernel runs the per-frame item code
     for fused in ('0', '1'):
         monkeypatch.setenv('RLSTED_FUSED', fused)
         plan = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
+        assert plan.strategy()['fused_rl'] == (fused == '1') and not plan.strategy()['frame_pairs']
         plan.set_object(np.broadcast_to(obj, (B, 512, 512)), 5e10 * 16)
         plan.simulate(seed=5)
         plan.iterate(7)
