@@ -1274,6 +1274,9 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         }
         v[s] = z;
     }
+    if constexpr (MODE == ROW_UPDATE) {
+        if (p.spec_out == nullptr) return;   // last iteration of a run: nobody reads the new estimate's spectrum (uniform)
+    }
     if constexpr (MODE != ROW_FWD) fft_sync<Cfg>(sync);   // the inverse's last LDS reads are done
     run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
     cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg + (size_t)row * p.pitch;

@@ -130,6 +130,8 @@ struct rl_deconv {
     // Richardson-Lucy loop of a single-view plan then runs on spectra [pairs][ny][lx] -- no Hermitian packing /
     // splitting around the row transforms.  The simulation and the H / H_t calls keep the per-frame layout.
     bool pair = false;
+    bool keep_last_spectrum = false;   // RLSTED_KEEP_LAST_SPECTRUM=1: every iteration ends with rowFFT(estimate)
+    bool drop_last_spectrum = false;   // set by run_slices for the last iteration of a long run: ROW_UPDATE skips rowFFT(estimate)
     void *psf_hat_pair = nullptr, *psf_hat_pair_re = nullptr;   // psf_hat at full width: [lx][ly] (transposed layout)
     void* spec_ones_pair = nullptr;                              // column-transformed spectrum of a pair of ones frames
     size_t n_spec_pair() const { return spec_image_elems(ny, lx); }
@@ -193,7 +195,7 @@ struct rl_deconv {
         for (int f0 = 0; f0 < frames; f0 += step) {
             const int nf = std::min(step, frames - f0);
             const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)(f0 / 2) * views * sp) : nullptr;
-            void* so = (char*)spec_out + (size_t)(f0 / 2) * views * sp;
+            void* so = spec_out ? (char*)spec_out + (size_t)(f0 / 2) * views * sp : nullptr;
             const void* sr = src ? (const char*)src + (size_t)f0 * views * im : nullptr;
             void* ds = dst ? (char*)dst + (size_t)f0 * im : nullptr;
             RL_TRY(dtype == RL_F32 ? row_pair_t<float>(mode, nf, si, so, sr, ds, nrm, in_mod, views)
@@ -613,7 +615,7 @@ struct rl_deconv {
                 RL_TRY(row_pair(ROW_RATIO, nf, sb, sb, m, nullptr, nullptr, 0, V));
             }
             RL_TRY(col_pair(sb, sa, np, COL_HT_FUSED));
-            RL_TRY(row_pair(ROW_UPDATE, nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            RL_TRY(row_pair(ROW_UPDATE, nf, sa, drop_last_spectrum ? nullptr : sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
             return RL_OK;
         }
         if (pair) {   // the whole iteration in the pair spectra, in place
@@ -626,7 +628,7 @@ struct rl_deconv {
                 RL_TRY(row_pair(ROW_RATIO, nf, sp, sp, off(meas, (size_t)f0 * n_img()), nullptr, nullptr));
             }
             RL_TRY(col_pair(sp, np, false));
-            RL_TRY(row_pair(ROW_UPDATE, nf, sp, sp, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            RL_TRY(row_pair(ROW_UPDATE, nf, sp, drop_last_spectrum ? nullptr : sp, nullptr, off(est, (size_t)f0 * n_img()), norm));
             return RL_OK;
         }
         void* sa = off(spec_a, (size_t)f0 * n_spec() * 2);
@@ -782,7 +784,14 @@ struct rl_deconv {
             }
             const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !use_fused && !sep;
             if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf, !shortcut);
-            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) rc = iterate_chunk(f0, nf, shortcut && i == 0, restart && i == 0);
+            // Frame pairs: the last iteration of a run of >= 4 does not transform its estimate forward again (1 of 2 row
+            // transforms of that launch, the spectrum store); an rl_deconv_iterate that continues rebuilds it with one ROW_FWD.
+            const bool drop = pair && k >= 4 && !keep_last_spectrum;
+            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) {
+                drop_last_spectrum = drop && i == k - 1;
+                rc = iterate_chunk(f0, nf, shortcut && i == 0, restart && i == 0);
+            }
+            drop_last_spectrum = false;
         }
         active = nullptr;
         if (ahead) {   // on errors a lane may not have waited for every slice: join the simulation stream too
@@ -805,6 +814,7 @@ struct rl_deconv {
             spec_valid = true;
             iterations = 0;
         }
+        if (pair && k >= 4 && !use_fused && !keep_last_spectrum) spec_valid = false;   // the last iteration left no spectrum behind
         iterations += k;
         return RL_OK;
     }
@@ -1156,6 +1166,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     if (getenv("RLSTED_Q_EXP_RATIO")) h->q_ratio = std::ldexp(1.0f, 14 - atoi(getenv("RLSTED_Q_EXP_RATIO")));
     if (getenv("RLSTED_ONES_SHORTCUT")) h->ones_shortcut = atoi(getenv("RLSTED_ONES_SHORTCUT")) != 0;
     if (getenv("RLSTED_FUSED")) h->fused = atoi(getenv("RLSTED_FUSED"));
+    if (getenv("RLSTED_KEEP_LAST_SPECTRUM")) h->keep_last_spectrum = atoi(getenv("RLSTED_KEEP_LAST_SPECTRUM")) != 0;
     if (getenv("RLSTED_FUSED_W")) h->fused_team = std::max(1, atoi(getenv("RLSTED_FUSED_W")));
     if (getenv("RLSTED_FUSED_WGS")) h->fused_wgs = std::max(1, atoi(getenv("RLSTED_FUSED_WGS")));
     if (getenv("RLSTED_FUSED_ACQ")) h->fused_acq = atoi(getenv("RLSTED_FUSED_ACQ")) != 0;

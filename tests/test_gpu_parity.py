@@ -464,7 +464,8 @@ def test_frame_pair_loop_equals_per_frame_loop(lib, ny, nx, B, monkeypatch):
         assert plan.strategy()['frame_pairs'] == (flag == '1' and info['ly'] in (256, 576) and info['lx'] in (256, 576))
         plan.set_object(x, 1e7)
         plan.simulate(seed=3)
-        plan.iterate(3)
+        plan.iterate(5)                      # a run of >= 4: its last iteration leaves no spectrum of the estimate behind ...
+        plan.iterate(1)                      # ... and a continuation rebuilds it
         a = plan.estimate()
         plan.forward(x)                      # clobbers the spectra: the next iterate rebuilds them from the estimate
         plan.iterate(2)
@@ -477,7 +478,7 @@ def test_frame_pair_loop_equals_per_frame_loop(lib, ny, nx, B, monkeypatch):
         assert max_rel(out['1'][i], out['0'][i]) < 1e-12, i
     d = orc.Deconvolver(psf)
     d.create_data_from_object(x[:1], noisy_measurement=[out['1'][3][:1, 0]])
-    for _ in range(3):
+    for _ in range(6):
         d.iterate()
     assert max_rel(out['1'][0][0], d.estimate[0]) < 1e-11
 
