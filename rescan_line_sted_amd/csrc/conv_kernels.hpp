@@ -1185,10 +1185,10 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 #endif
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
-    static_assert(Cfg::T == 64, "pair rows need wave-private transforms");
+    static_assert(Cfg::T == 64 || Q == 1, "one transform per wave, or one (workgroup-synchronous) transform per workgroup");
     static_assert(!RL_SPEC_BLOCKED, "row-major spectra only");
     static_assert(MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE, "pair modes");
-    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value, VMAX = CfgRegs<Cfg>::VMAX;
+    constexpr int NP = Cfg::NP, L = Cfg::L, TT = Cfg::T, LP = LdsSlots<Cfg>::value, VMAX = CfgRegs<Cfg>::VMAX;
     using I0 = PassInfo<Cfg, true, 0>;        // spectrum side, on the way in
     using F0 = PassInfo<Cfg, false, 0>;       // image side
     using FL = PassInfo<Cfg, false, NP - 1>;  // spectrum side, on the way out
@@ -1196,17 +1196,17 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     static_assert(I0::R == FL::R && I0::NBF == FL::NBF && I0::TAIL == FL::TAIL && I0::NBM == FL::NBM, "spectrum-side layouts must agree");
     static_assert(IL::R == F0::R && IL::NB == F0::NB && !F0::TAIL, "image-side layouts must agree");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
-    const int q = rl_uniform(tid / 64);
-    const int t = tid % 64;
+    const int q = rl_uniform(tid / TT);
+    const int t = tid % TT;
     const int row = bx * Q + q;
-    if (row >= p.ny) return;   // whole wave; no workgroup barrier below
-    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + q * LP};
+    if (row >= p.ny) return;   // a whole wave (wave-private transforms) or the whole workgroup (Q == 1): no barrier is missed
+    LdsView<T, 1, LdsGather<L>::value, LdsPadShift<L>::value> view_lds{lds + q * LP};
     const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
     // by = pair * V + view (ROW_RATIO of a multi-view plan: measurement images are [frame][view]); V = 1 otherwise
     const int pr = by / p.V, vw = by % p.V;
     const bool okb = 2 * pr + 1 < p.frames;
     const size_t ra = ((size_t)(2 * pr * p.V + vw) * p.ny + row) * p.nx, rb = okb ? ra + (size_t)p.V * rimg : ra;   // frame a / b, this row
-    const int tail_k = (64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF;
+    const int tail_k = (64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF;   // (TAIL passes exist for T == 64 only)
 
     // operands of the pointwise stage: measurement / estimate requested ahead of the inverse transform, the normaliser
     // (an L2 hit: one image shared by all frames) ahead of it too or right behind it (RL_PAIR_NRM_EARLY: registers against waits)
@@ -1219,8 +1219,8 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int i = (t + nb * 64) + r * NBF;
-                const bool inx = (t + nb * 64) < NBF && i < p.nx;
+                const int i = (t + nb * TT) + r * NBF;
+                const bool inx = (t + nb * TT) < NBF && i < p.nx;
                 pre[nb * R + r] = inx ? mk<T>(s0[i], s1[i]) : mk<T>((T)0, (T)0);
             }
     }
@@ -1231,8 +1231,8 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int i = (t + nb * 64) + r * NBF;
-                    nrm[nb * R + r] = ((t + nb * 64) < NBF && i < p.nx) ? n0[i] : (T)1;
+                    const int i = (t + nb * TT) + r * NBF;
+                    nrm[nb * R + r] = ((t + nb * TT) < NBF && i < p.nx) ? n0[i] : (T)1;
                 }
         }
     };
@@ -1245,7 +1245,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         for (int nb = 0; nb < I0::NBM; ++nb)
 #pragma unroll
             for (int r = 0; r < I0::R; ++r) {
-                const int j = t + nb * 64;
+                const int j = t + nb * TT;
                 v[nb * I0::R + r] = j < I0::NBF ? rl_ldg(sync, si + (j + r * I0::NBF)) : mk<T>((T)0, (T)0);
             }
         if constexpr (I0::TAIL) tl = rl_ldg(sync, si + tail_k);
@@ -1255,8 +1255,8 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 #pragma unroll
     for (int s = 0; s < NB * R; ++s) {
         const int nb = s / R, r = s % R;
-        const int i = (t + nb * 64) + r * NBF;
-        const bool inx = (t + nb * 64) < NBF && i < p.nx;
+        const int i = (t + nb * TT) + r * NBF;
+        const bool inx = (t + nb * TT) < NBF && i < p.nx;
         cx<T> z = mk<T>((T)0, (T)0);
         if constexpr (MODE == ROW_FWD) {
             z = mk<T>(pre[s].re, okb ? pre[s].im : (T)0);
@@ -1284,7 +1284,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     for (int nb = 0; nb < FL::NBM; ++nb)
 #pragma unroll
         for (int r = 0; r < FL::R; ++r) {
-            const int j = t + nb * 64;
+            const int j = t + nb * TT;
             if (j < FL::NBF) so[j + r * FL::NBF] = rl_spec_round(v[nb * FL::R + r], p.qscale);
         }
     if constexpr (FL::TAIL) so[tail_k] = rl_spec_round(tl, p.qscale);

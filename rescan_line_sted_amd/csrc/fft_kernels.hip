@@ -356,18 +356,18 @@ static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hip
 
 // frame-pair row kernels (rowpair_body)
 template <int L, int Q, int MODE, typename T>
-__global__ void __launch_bounds__(64 * Q, (row_min_waves<L, MODE == ROW_FWD ? ROW_RATIO : MODE, true, T>())) k_rowpair(const RowParams<T> p) {
+__global__ void __launch_bounds__(CfgFor<L>::Cfg::T * Q, (row_min_waves<L, MODE == ROW_FWD ? ROW_RATIO : MODE, true, T>())) k_rowpair(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
-    if constexpr (WavePrivate<KCfg>::value)
+    if constexpr (WavePrivate<KCfg>::value || Q == 1)
         rowpair_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 template <int Q, typename T>
 static hipError_t launch_row_pair_t(int mode, const void* params, unsigned gy, hipStream_t s) {
-    if constexpr (WavePrivate<Cfg>::value) {
+    if constexpr (WavePrivate<Cfg>::value || Q == 1) {
         const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
-        const dim3 grid((unsigned)((p.ny + Q - 1) / Q), gy), block(64 * Q);
+        const dim3 grid((unsigned)((p.ny + Q - 1) / Q), gy), block(Cfg::T * Q);
         const size_t lds = (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>);
         if (mode == ROW_FWD) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_FWD, T>, grid, block, lds, s, p);
         else if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T>, grid, block, lds, s, p);
@@ -441,6 +441,8 @@ static hipError_t launch_row(int dtype, int mode, const void* params, unsigned g
 #define RL_PAIR_Q32 8
 #endif
 constexpr int kPairQ32 = WavePrivate<Cfg>::value ? RL_PAIR_Q32 : kQ32;
+// frame-pair row kernels exist for one transform per wave and for one workgroup-synchronous transform per workgroup
+constexpr bool kPairRows = WavePrivate<Cfg>::value || (kQ32 == 1 && kQ64 == 1);
 static hipError_t launch_row_pair(int dtype, int mode, const void* params, unsigned gy, hipStream_t s) {
     return dtype == DT_F32 ? launch_row_pair_t<kPairQ32, float>(mode, params, gy, s)
                            : launch_row_pair_t<kQ64, double>(mode, params, gy, s);
@@ -463,7 +465,7 @@ static hipError_t prepare_rows() {
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, true, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, false, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, true, T>, b)) != hipSuccess) return e;
-    if constexpr (WavePrivate<Cfg>::value) {
+    if constexpr (kPairRows) {
         constexpr int QP = sizeof(T) == 4 ? kPairQ32 : Q;
         const size_t bp = lds_bytes<QP, T>();
         if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_FWD, T>, bp)) != hipSuccess) return e;
@@ -523,7 +525,7 @@ const KernelTable* RL_TABLE_FN() {
                                   WavePrivate<CCfg>::value ? launch_col_stream : nullptr,
                                   WavePrivate<Cfg>::value ? launch_row_stream : nullptr,
                                   (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) ? launch_fused : nullptr,
-                                  WavePrivate<Cfg>::value ? launch_row_pair : nullptr};
+                                  kPairRows ? launch_row_pair : nullptr};
     return &t;
 }
 

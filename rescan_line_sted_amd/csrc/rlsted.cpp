@@ -1100,7 +1100,12 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     // batch (a pair's two frames share rounding errors: 1e-16-level differences with the partner frame).
     // Multi-view plans: built and tested (RLSTED_PAIR=1), no gain (512^2, 4 views: 30.0 ms per 64 frames x 20 iterations either
     // way -- the multi-view column kernels set the pace), so the default pairs single-view plans only.
-    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32 && V == 1);
+    // Long transforms (L >= 1152, one workgroup-synchronous row transform per workgroup): built and tested too, 2048^2 -3.5 %,
+    // 4096^2 -12 % time per iteration -- but the per-frame loop's Hermitian split averages the two mirrored halves of every
+    // row spectrum, the pair loop does not, and where f32 has no margin left that shows: white noise at 2048^2, K = 20,
+    // 8.8e-6 -> 1.05e-5 against the f64 plan.  Default there: per frame (RLSTED_PAIR=1 pairs them).
+    const bool short_rows = h->tx->T == 64;
+    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32 && V == 1 && short_rows);
     const bool pair_views_ok = V == 1 ? h->inplace
                                       : (h->fuse_views && h->wave_private_y() && h->n_spec() * 2 <= V * h->n_img());   // (frame spectra fit scratch)
     // (an explicitly requested fused kernel or streaming flavour keeps the per-frame layout they are written for)
