@@ -220,12 +220,15 @@ size_t sep2d_lds(int py, int px, int V) {
 template <typename T, int MODE, int TH>
 hipError_t sep2d_launch(const void* in, const void* uf, const void* vf, const void* aux, const void* norm, void* dst, int frames,
                         int ny, int nx, int py, int px, int V, hipStream_t s) {
-    static bool allowed = false;
+    static unsigned long long allowed_devices = 0;   // the attribute is per device: one bit per device id
     const size_t lds = sep2d_lds<T, TH>(py, px, V);
-    if (!allowed) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_sep2d<T, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSep2dMaxLds);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !(allowed_devices >> dev & 1ull)) {
+        e = hipFuncSetAttribute((const void*)k_sep2d<T, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSep2dMaxLds);
         if (e != hipSuccess) return e;
-        allowed = true;
+        if (dev >= 0 && dev < 64) allowed_devices |= 1ull << dev;
     }
     const dim3 grid((unsigned)((nx + kColW - 1) / kColW), (unsigned)((ny + TH - 1) / TH), (unsigned)frames);
     k_sep2d<T, MODE, TH><<<grid, 256, lds, s>>>((const T*)in, (const T*)uf, (const T*)vf, (const T*)aux, (const T*)norm, (T*)dst, ny, nx, py, px, V);
