@@ -1109,7 +1109,9 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     const bool pair_views_ok = V == 1 ? h->inplace
                                       : (h->fuse_views && h->wave_private_y() && h->n_spec() * 2 <= V * h->n_img());   // (frame spectra fit scratch)
     // (an explicitly requested fused kernel or streaming flavour keeps the per-frame layout they are written for)
-    if (want_pair && !h->sep && !h->fused && h->streaming == 0 && pair_views_ok && h->B % 2 == 0 && h->tx->launch_row_pair && h->psf_transposed()) {
+    // an odd batch leaves its last pair half empty: allowed where the pair spectra still fit the per-frame buffers
+    const bool pair_fits = ((size_t)(h->B + 1) / 2) * h->n_spec_pair() <= (size_t)h->B * h->n_spec();
+    if (want_pair && !h->sep && !h->fused && h->streaming == 0 && pair_views_ok && pair_fits && h->tx->launch_row_pair && h->psf_transposed()) {
         const size_t nz = V * (size_t)h->lx * h->ly;
         void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
         RL_TRY(ctx->plain_twiddles(h->ly, &wy));
