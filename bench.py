@@ -9,6 +9,7 @@ Deconvolver.create_data_from_object + 20 x Deconvolver.iterate of the reference
 resident in HBM when the timed region starts; nothing crosses PCIe inside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f32|f64] [--size 512|2048]
+                    [--workload headline|fig2sweep]
 
 --gpus N > 1 without a launcher: this process starts `python -m torch.distributed.run
 --nproc-per-node N` on itself (before anything touches the GPU) and relays the ranks' one JSON
@@ -19,7 +20,12 @@ The barrier, the reduction and the gather are the C ABI's (rl_comm_*, rl_gather*
 librlsted.so itself); torch.distributed is only the fallback transport should that fail to start.
 
 --size 2048 is BASELINE config 3 (synthetic 2048x2048 object, line-rescan, 4 views); the default single-GPU run
-also carries three steps of it as "size_2048" in the same JSON line (--no-2048 skips them).
+also carries short legs of it ("size_2048"), of config 2's other half (512x512 line-rescan, 4 views: "line_rescan_512")
+and of the reference's own arithmetic (512x512 point, float64 plan: "f64_512") in the same JSON line (--no-extra-legs
+skips them).  With N > 1 ranks (or --workload fig2sweep) the line also carries "fig2_sweep": BASELINE config 4 -- 4 test
+objects x 6 doses x 3 scan modes x 16 seeds = 1152 tasks, K = 20 -- cut into cost-weighted shards by
+sharding.partition, each rank running its shard through rl_batch_run, ONE gather of the estimates on rank 0
+(rl_comm_gather_host), the gather timed separately.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -42,13 +48,19 @@ ERROR_DEFINITION = ('normwise: max|a-b| / max|b| over the frame; pixelwise: max 
                     '|a-b| / b; a = device estimate, b = float64 oracle on the device-drawn noisy measurement')
 
 
-def workload(size):
+def workload(size, n_views=None):
     """512: BASELINE config[1] restricted to the metric's quoted case -- astronaut 128x128 -> 512x512
     (np.kron x4), point-descan STED PSF of the 2.0x operating point (107x107,
     line_sted_figure_2.py:107-120,235-238), brightness 5e10*16.
     2048: config[2] -- default_rng(1234) uniform [0,255) object, the 4 line-rescan views of the same
     operating point, brightness 5e10*256 (the same ~1e7 counts per pixel)."""
     psfs = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
+    if size == 512 and (n_views or 1) > 1:      # config 2's other half: astronaut, line-rescan, 4 orientations
+        objs = np.load(os.path.join(ROOT, 'tests', 'golden', 'objects.npz'))
+        obj = np.kron(objs['astronaut'].astype(np.float64), np.ones((1, 4, 4)))[0]
+        psf = [p[None] for p in psfs['2p0x_lr/line_sted_psfs'][:, 0]]
+        return obj, psf, 5e10 * 16, ('astronaut 128->512x512 (np.kron x4), line-rescan STED, 4 views 107x107 (2.0x operating point), '
+                                     'simulate (H + Philox Poisson) + 20 RL iterations per frame (BASELINE config 2, line-rescan half)')
     if size == 512:
         objs = np.load(os.path.join(ROOT, 'tests', 'golden', 'objects.npz'))
         obj = np.kron(objs['astronaut'].astype(np.float64), np.ones((1, 4, 4)))[0]
@@ -179,6 +191,16 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, local, counts, root=0):
+        """Host arrays, counts[r] items from rank r (sharding.RcclComm.gather's contract)."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        parts = [None] * self.world if self.rank == root else None
+        self.dist.gather_object(local, parts, dst=root)
+        if self.rank != root:
+            return None
+        parts = [p for p, c in zip(parts, counts) if c > 0]
+        return np.concatenate(parts) if parts else np.zeros((0,))
+
     def gather_plan(self, plan, counts, which='estimate', root=0, to_host=True):
         t = self.torch.as_tensor(plan.device_array(which), device=self.dev) if self.cuda else self.torch.from_numpy(plan.estimate())
         bufs = [self.torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
@@ -251,31 +273,100 @@ def accuracy(plan, psf, size, dtype):
             'contract': 1e-5 if dtype == 'f32' else 1e-10}
 
 
-def second_size(size, B, steps, warmup, device):
-    """`steps` whole cycles (simulate + 20 RL iterations) of `B` frames of the --size 2048 workload, timed like
-    the headline (synchronise, wall clock, synchronise)."""
+def extra_leg(size, n_views, dtype, B, steps, warmup, device):
+    """`steps` whole cycles (simulate + 20 RL iterations) of `B` frames of another workload shape, timed like the
+    headline (synchronise, wall clock, synchronise): BASELINE config 3 (2048 x 2048 line-rescan), config 2's line-rescan
+    half (512 x 512, 4 views) and the headline in the reference's own arithmetic (float64 plan)."""
     from rescan_line_sted_amd import _lib
-    obj, psf, brightness, name = workload(size)
-    plan = _lib.DeconvPlan(psf, B, size, size, dtype='f32', device=device)
+    obj, psf, brightness, name = workload(size, n_views)
+    plan = _lib.DeconvPlan(psf, B, size, size, dtype=dtype, device=device)
     plan.set_object(np.broadcast_to(obj, (B, size, size)), brightness)
     for w in range(warmup):
         plan.bench_cycles(K_ITERS, 1, seed=w)
     plan.ctx.synchronize()
     t0 = time.perf_counter()
-    for s in range(steps):
-        plan.bench_cycles(K_ITERS, 1, seed=warmup + s)
+    plan.bench_cycles(K_ITERS, steps, seed=warmup)
     plan.ctx.synchronize()
     el = time.perf_counter() - t0
     est = plan.estimate()
     assert np.isfinite(est).all() and est.min() >= 0
     value = B * steps / el
-    alg = algorithmic_bytes_per_frame(size * size, len(psf), K_ITERS)
+    es = 4 if dtype == 'f32' else 8
+    alg = algorithmic_bytes_per_frame(size * size, len(psf), K_ITERS) * es // 4
     info = plan.info()
     return {'metric': 'simulated frames/s (%dx%d, 20 RL iters)' % (size, size), 'value': value, 'unit': 'frames/s',
-            'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3, 'dtype': 'f32',
+            'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3, 'dtype': dtype,
             'config': {'workload': name, 'frames_per_gpu_per_step': B, 'n_psf': len(psf), 'rl_iters': K_ITERS,
-                       'fft': '%dx%d' % (info['ly'], info['lx'])},
-            'whole_path': {'algorithmic_bytes_per_frame': alg, 'GBps': alg * value / 1e9, 'frac': alg * value / 1e9 / HBM_PEAK_GBS}}
+                       'fft': '%dx%d' % (info['ly'], info['lx']), 'frame_pairs': plan.strategy()['frame_pairs']},
+            'whole_path': {'algorithmic_bytes_per_frame': alg, 'bytes_per_element': es, 'GBps': alg * value / 1e9,
+                           'frac': alg * value / 1e9 / HBM_PEAK_GBS}}
+
+
+# ------------------------------------------------------------------ BASELINE config 4: the sharded figure-2 sweep
+def fig2_psf_sets(stub):
+    """The 18 PSF sets of the sweep: 6 doses x (point-descan, line-descanned, line-rescanned), 1 ... 10 views
+    (line_sted_figure_2.py:77-162), made by the product on this rank's device (tune_psf, psf_report, rotations)."""
+    doses = ('1p0x', '1p5x', '2p0x', '2p5x', '3p0x', '4p0x')
+    if stub:      # CPU control-flow tests: shapes only
+        views = {'_point': [1] * 6, '_ld': [1, 3, 4, 6, 8, 10], '_lr': [2, 3, 4, 6, 8, 10]}
+        return {d + k: [np.ones((1, 7, 7))] * v[i] for k, v in views.items() for i, d in enumerate(doses)}
+    from rescan_line_sted_amd import psf
+    sets, _ = psf.figure_2_psfs([d + s for d in doses for s in ('_ld', '_lr')])
+    out = {}
+    for d in doses:
+        out[d + '_point'] = [np.asarray(p) for p in sets[d + '_lr_point_sted']]
+        for sfx in ('_ld', '_lr'):
+            key, = [k for k in sets if k.startswith(d + sfx + '_line_')]
+            out[d + sfx] = [np.asarray(p) for p in sets[key]]
+    return out
+
+
+def fig2_sweep_leg(comm, rank, world, device, stub):
+    """Config 4 end to end: cost-weighted partition of the 1152 tasks over the ranks (sharding.partition), this rank's
+    shard through sweep.run_tasks (rl_batch_run), one gather on rank 0; run and gather timed separately, maxima over
+    ranks.  No collective in the data path."""
+    from rescan_line_sted_amd import sharding, sweep
+    objs = np.load(os.path.join(ROOT, 'tests', 'golden', 'objects.npz'))
+    objects = {n: objs[n][0].astype(np.float64) for n in ('astronaut', 'cat', 'lines', 'rings')}
+    t0 = time.perf_counter()
+    psf_sets = fig2_psf_sets(stub)
+    t_psf = time.perf_counter() - t0
+    tasks = sweep.make_tasks(objects, psf_sets, range(16))
+    costs = sweep.task_costs(tasks, objects, psf_sets, K_ITERS)
+    shards = sharding.partition(costs, world)
+    mine = [tasks[i] for i in shards[rank]]
+    big = (max(o.shape[0] for o in objects.values()), max(o.shape[1] for o in objects.values()))
+
+    def run(ts):
+        if stub:
+            time.sleep(0.001 * len(ts))
+            return [np.ones(objects[o].shape) for o, _, _ in ts]
+        return sweep.run_tasks(ts, objects, psf_sets, K_ITERS, 5e10, 'f32', device)
+    if not stub:
+        run(mine[:4])                       # library / plan warm-up
+    if comm is not None:
+        comm.barrier()
+    t0 = time.perf_counter()
+    local = sweep.pad_stack(run(mine), big)
+    t_run = time.perf_counter() - t0
+    gathered, t_gather = local, 0.0
+    if comm is not None:
+        t_run = comm.allreduce_max(t_run)
+        comm.barrier()
+        t0 = time.perf_counter()
+        gathered = comm.gather(local, [len(sh) for sh in shards], 0)
+        t_gather = time.perf_counter() - t0
+    out = {'workload': 'BASELINE config 4: 4 test objects x 6 doses x 3 scan modes x 16 seeds, simulate + %d RL iterations, f32' % K_ITERS,
+           'tasks': len(tasks), 'tasks_per_rank': [len(sh) for sh in shards],
+           'cost_per_rank_rel': [round(sum(costs[i] for i in sh) / (sum(costs) / world), 4) for sh in shards],
+           'seconds_run_max_over_ranks': t_run, 'frames_per_s': len(tasks) / t_run, 'gather_ms': t_gather * 1e3,
+           'gather_bytes': int(len(tasks) * big[0] * big[1] * 8), 'psf_sets_seconds': t_psf,
+           'partition': 'sharding.partition (greedy longest-processing-time, cost = pixels x views x (2 + 2K))'}
+    if rank == 0:
+        full = sharding.unshard(shards, gathered) if comm is not None else gathered
+        assert full.shape[0] == len(tasks) and np.isfinite(full).all()
+        out['frames_on_root'] = int(full.shape[0])
+    return out
 
 
 def main():
@@ -283,12 +374,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=None, help='frames per GPU per step (default 256; 32 at --size 2048)')
+    ap.add_argument('--batch', type=int, default=None, help='frames per GPU per step (default 1024; 32 at --size 2048)')
+    ap.add_argument('--workload', default='headline', choices=('headline', 'fig2sweep'),
+                    help='fig2sweep: also run BASELINE config 4 (the sharded figure-2 sweep; always run when N > 1)')
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--size', type=int, default=512, choices=(512, 2048))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true')
-    ap.add_argument('--no-2048', action='store_true', help='skip the short 2048 x 2048 leg of the default run')
+    ap.add_argument('--no-extra-legs', '--no-2048', dest='no_extra', action='store_true',
+                    help='skip the short 2048 x 2048, 512 x 512 line-rescan and float64 legs of the default run')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -307,13 +401,14 @@ def main():
         raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
     stub = os.environ.get('RLSTED_BENCH_STUB') == '1'
     size = args.size
-    B = args.batch or (256 if size == 512 else 32)
+    # 1024 frames per step: the driver's 20 timed steps are then > 1 s of device time (256 frames: 0.27 s)
+    B = args.batch or (1024 if size == 512 else 32)
     obj, psf, brightness, workload_name = workload(size)
 
     # CPU legs first: this process has not touched the GPU yet, the workers are plain children
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
-        cpu = cpu_baseline(size, 10.0 if size == 512 else 20.0)
+        cpu = cpu_baseline(size, 6.0 if size == 512 else 20.0)
 
     comm, transport = (None, None)
     if world > 1 or 'RANK' in os.environ:
@@ -364,49 +459,38 @@ def main():
     est = plan.estimate()
     assert np.isfinite(est).all() and est.min() >= 0
 
-    # ---- roofline of the dominant kernel: in-situ HIP-event durations of one whole cycle (every launch
-    # bracketed by events on the stream it goes to, slices overlapping as in the timed steps)
+    # ---- roofline: in-situ HIP-event durations of one whole cycle (every launch bracketed by the kernel's own
+    # begin / end events on the stream it goes to, slices overlapping as in the timed steps)
     kt, FL = plan.time_cycle(K_ITERS, seed=4242)
     n_pix, V = size * size, len(psf)
     info = plan.info()
-    es = 4 if args.dtype == 'f32' else 8
     avg = {k: v[0] for k, v in kt.items()}
-    if 'rl_fused' in avg:        # one launch runs all iterations of all frames
-        dom = 'rl_fused'
-        launch_bytes = 4 * n_pix * (3 * V + 4) * K_ITERS * FL
-        achieved = launch_bytes / (avg[dom] * 1e-3) / 1e9
-        iter_ms = avg[dom] / K_ITERS
-        alg_iter = launch_bytes / K_ITERS
-    else:
-        total_ms = {k: kt[k][0] * kt[k][1] for k in ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE')}
-        kernel_ms = {'colconv': total_ms['colconv_H'] + total_ms['colconv_Ht'], 'rowpass_RATIO': total_ms['rowpass_RATIO'],
-                     'rowpass_UPDATE': total_ms['rowpass_UPDATE']}
-        dom = max(kernel_ms, key=kernel_ms.get)
-        iter_ms = avg['colconv_H'] + avg['rowpass_RATIO'] + avg['colconv_Ht'] + avg['rowpass_UPDATE']
-        alg_iter = 4 * n_pix * (3 * V + 4) * FL     # algorithmic bytes of one RL iteration over one slice
-        # Algorithmic bytes exist per PASS: pass 1 (H + ratio) moves 4N(2V+1), pass 2 (H_t +
-        # update) 4N(V+3); each pass is one column launch + one row launch and cannot be split between them.
-        # achieved = pass bytes / (the pass's two launches); for k_colconv, launched once in each pass, the
-        # average over its two passes.
-        if dom == 'colconv':
-            launch_bytes, pass_ms = alg_iter / 2, iter_ms / 2
-        elif dom == 'rowpass_RATIO':
-            launch_bytes, pass_ms = 4 * n_pix * (2 * V + 1) * FL, avg['colconv_H'] + avg['rowpass_RATIO']
-        else:
-            launch_bytes, pass_ms = 4 * n_pix * (V + 3) * FL, avg['colconv_Ht'] + avg['rowpass_UPDATE']
-        achieved = launch_bytes / (pass_ms * 1e-3) / 1e9
-    # fabric bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE,
-    # separate rocprofv3 passes, gfx950 correction applied): measured offline with the command recorded
-    # in the file, valid for this exact launch shape only.
-    traffic = None
-    for rnd in ('r02', 'r01'):
+    rl_kernels = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE')
+    total_ms = {k: kt[k][0] * kt[k][1] for k in rl_kernels}
+    kernel_ms = {'colconv': total_ms['colconv_H'] + total_ms['colconv_Ht'], 'rowpass_RATIO': total_ms['rowpass_RATIO'],
+                 'rowpass_UPDATE': total_ms['rowpass_UPDATE']}
+    dom = max(kernel_ms, key=kernel_ms.get)
+    # Algorithmic bytes exist per RL ITERATION: 4N(3V+4) per frame -- pass 1 (H + ratio) 4N(2V+1), pass 2
+    # (H_t + update) 4N(V+3); each pass is one column launch + one row launch and cannot be split between its two
+    # kernels.  So the roofline is quoted on the unit the bytes are defined for: one RL iteration over one slice of
+    # the batch = the four launches colconv, ROW_RATIO, colconv, ROW_UPDATE; `achieved` = its algorithmic bytes / the sum
+    # of the four launches' average durations, `traffic` = the sum of the four launches' fabric bytes from the PMC
+    # counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950 correction applied: tools/pmc_traffic.py,
+    # recorded offline for this exact launch shape).  The dominant kernel's own share is in `dominant_kernel`.
+    iter_ms = sum(avg[k] for k in rl_kernels)
+    alg_iter = 4 * n_pix * (3 * V + 4) * FL
+    achieved = alg_iter / (iter_ms * 1e-3) / 1e9
+    traffic, per_kernel_traffic, pmc_file = None, None, None
+    for rnd in ('r03', 'r02'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')))
         except (OSError, ValueError):
             continue
         if (pmc.get('frames_per_launch') == FL and pmc.get('dtype') == args.dtype and pmc.get('n_psf') == V
-                and pmc.get('shape') == [size, size] and dom in pmc):
-            traffic = pmc[dom].get('fabric_bytes_per_launch', pmc[dom].get('hbm_bytes_per_launch'))
+                and pmc.get('shape') == [size, size] and all(k in pmc for k in rl_kernels)):
+            per_kernel_traffic = {k: pmc[k]['fabric_bytes_per_launch'] for k in rl_kernels}
+            traffic = sum(per_kernel_traffic.values())
+            pmc_file = 'profiles/%s/pmc_traffic.json' % rnd
             break
     alg_frame = algorithmic_bytes_per_frame(n_pix, V, K_ITERS)
     # The batch slices run on two streams: on average `concurrency` kernels are in flight, each with its
@@ -414,15 +498,17 @@ def main():
     busy_ms = sum(v[0] * v[1] for v in kt.values())
     concurrency = max(1.0, busy_ms / max(dev_ms / args.steps, 1e-9))
     roofline = {
-        'bound': 'hbm', 'kernel': dom, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
-        'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+        'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+        'kernel': 'one RL iteration over one slice = 4 launches: k_colconv, k_rowpair<RATIO>, k_colconv, k_rowpair<UPDATE>',
+        'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
+        'algorithmic_bytes': alg_iter, 'traffic': traffic, 'traffic_over_algorithmic': traffic / alg_iter if traffic else None,
+        'traffic_per_kernel': per_kernel_traffic, 'traffic_source': pmc_file,
+        'per': 'RL iteration over %d frames (the slice every launch of the loop covers)' % FL,
+        'dominant_kernel': {'name': dom, 'share_of_rl_kernel_time': kernel_ms[dom] / sum(kernel_ms.values())},
         'kernels_in_flight': concurrency, 'frac_per_chip_share': achieved * concurrency / HBM_PEAK_GBS,
-        'algorithmic_bytes_per_launch': launch_bytes,
         'timing': 'kernel begin/end HIP events (hipExtLaunchKernelGGL) on every launch of one whole cycle, slices overlapping on their streams as in the timed steps (rl_deconv_time_cycle)',
         'kernel_avg_ms': avg, 'kernel_launches_per_cycle': {k: v[1] for k, v in kt.items()},
-        'frames_per_launch': FL,
-        'rl_iteration': {'ms': iter_ms, 'algorithmic_GBps': alg_iter / (iter_ms * 1e-3) / 1e9,
-                         'frac': alg_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        'frames_per_launch': FL, 'frame_pairs': plan.strategy()['frame_pairs'] if not stub else None,
         'whole_path': {'algorithmic_bytes_per_frame': alg_frame, 'GBps': alg_frame * (value / world) / 1e9,
                        'frac': alg_frame * (value / world) / 1e9 / HBM_PEAK_GBS},
     }
@@ -442,14 +528,22 @@ def main():
         out['accuracy'] = accuracy(plan, psf, size, args.dtype)
     if cpu is not None:
         out['cpu_baseline'] = cpu
-    # the north star's second reporting size in the same record: a few steps of BASELINE config 3's shape
-    # (2048 x 2048, line-rescan, 4 views); single-process runs only -- the N-rank runs measure the headline
-    if size == 512 and world == 1 and comm is None and not stub and not args.no_2048 and args.dtype == 'f32':
+    # further shapes in the same record, a few steps each (single-process runs only -- the N-rank runs measure the
+    # headline): BASELINE config 3 (2048^2 line-rescan), config 2's line-rescan half, the reference's float64 arithmetic
+    if size == 512 and world == 1 and comm is None and not stub and not args.no_extra and args.dtype == 'f32':
+        del plan
+        for key, leg in (('size_2048', (2048, 4, 'f32', 32, 3, 1)), ('line_rescan_512', (512, 4, 'f32', 128, 5, 1)),
+                         ('f64_512', (512, 1, 'f64', 128, 5, 1))):
+            try:
+                out[key] = extra_leg(*leg, local_rank)
+            except Exception as exc:     # reported, never allowed to void the headline
+                out[key] = {'error': repr(exc)}
+    # BASELINE config 4 through the sharder: whenever there is more than one rank, or on request
+    if world > 1 or args.workload == 'fig2sweep':
         try:
-            del plan
-            out['size_2048'] = second_size(2048, 32, 3, 1, local_rank)
-        except Exception as exc:     # reported, never allowed to void the headline
-            out['size_2048'] = {'error': repr(exc)}
+            out['fig2_sweep'] = fig2_sweep_leg(comm, rank, world, local_rank, stub)
+        except Exception as exc:
+            out['fig2_sweep'] = {'error': repr(exc)}
     if comm is not None:
         assert out['n_gpus'] == args.gpus
         if gather and rank == 0 and 'frames_on_root' in gather:

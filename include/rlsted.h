@@ -136,10 +136,14 @@ int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements
 /* Convolution strategy the plan chose for its PSF set: separable != 0: every view
  * is rank 1 (p = u v^T; the 0 / 90 degree line PSFs) and small, H / H_t run as direct row + column stencils;
  * otherwise the FFT path, with real_psf_spectrum != 0 when the (point-symmetric) PSFs' spectra are real and
- * the column kernels multiply by their real parts alone; fused_rl != 0: RLSTED_FUSED selected the persistent
- * XCD-resident Richardson-Lucy kernel; frame_pairs != 0: the Richardson-Lucy loop transforms frames 2p and 2p+1
- * as the real and imaginary part of one complex image (single view, even batch, f32 by default: RLSTED_PAIR) --
- * a frame's estimate then depends on its partner at rounding level.  Any of the pointers may be NULL.      */
+ * the column kernels multiply by their real parts alone; *fused_rl is always 0 (the persistent XCD-resident
+ * Richardson-Lucy kernel of round 2 was measured, lost and removed; the parameter keeps the signature);
+ * frame_pairs != 0: the Richardson-Lucy loop transforms frames 2p and 2p+1 as the real and imaginary part of one
+ * complex image (single-view f32 plans by default: RLSTED_PAIR) -- a frame's estimate then depends on its partner
+ * at f32 rounding level (~1e-7 of the brighter partner's scale).  The answer is the loop that will run on the
+ * CURRENT data: a plan built with pairs runs its per-frame loop while any pair's frames differ in level (sum of the
+ * object / measurement) by more than a factor of 4 (RLSTED_PAIR_MAX_RATIO), because a dim frame would inherit
+ * the rounding error of a bright partner.  Any of the pointers may be NULL.                                  */
 int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl, int* frame_pairs);
 
 /* Plan geometry: frames per plan, views per frame, image shape.                */
@@ -153,7 +157,10 @@ int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx)
  * (rl_deconv_simulate_keyed).  rl_batch_run works through n_tasks tasks in chunks of the plan's
  * batch: objects -> H -> Poisson -> k_iters Richardson-Lucy iterations from estimate = 1, and
  * writes the estimates [n_tasks][ny][nx] to estimates_out (NULL: the last chunk stays in the
- * plan's buffers for rl_gather).  A task's result does not depend on its position in the list. */
+ * plan's buffers for rl_gather).  A task's noiseless and noisy measurements do not depend on its position in the
+ * list (per-task Philox key); its estimate does not either in f64 plans, and in f32 plans only at rounding level
+ * (~1e-7: frame pairs share a transform with their neighbour in the batch -- and only with a neighbour of
+ * comparable level, see rl_deconv_strategy).                                                                  */
 typedef struct rl_task {
     const double* object;
     double total_brightness;
@@ -213,6 +220,14 @@ int rl_gaussian_filter(rl_ctx* ctx, const double* in, double* out, int nz, int n
 int rl_psf_generate(rl_ctx* ctx, int psf_type, int ny, int nx, double excitation_brightness,
                     double depletion_brightness, double blur_sigma, int rescan_ratio,
                     double* arrays_out, double* rows_out, double* scalars_out);
+
+/* The two intermediate arrays of the 'line' branch that generate_psfs(output_dir=...) also writes (:339-341):
+ * emission_psf_out [ny][nx] = gaussian_filter(centred delta, blur_sigma) (:258-260) and rescan_unscaled_out
+ * [ny][rescan_ratio * nx] = rescanned_signal_cumu, the detector ring before it is rolled and binned (:266-298).
+ * rescan_ratio: the integer ratio a previous rl_psf_generate of the same parameters reported (scalars_out[0]); it
+ * sizes the second buffer.  Either pointer may be NULL.                                                      */
+int rl_psf_generate_line_extras(rl_ctx* ctx, int ny, int nx, double excitation_brightness, double depletion_brightness,
+                                double blur_sigma, int rescan_ratio, double* emission_psf_out, double* rescan_unscaled_out);
 
 /* psf_report (:75-166).  report_out[8] = { resolution_improvement_descanned,
  * resolution_improvement_rescanned (NaN for 'point'), excitation_dose,
@@ -291,7 +306,7 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms);
  * the batch slices overlapping on their streams as in production -- the figure a rocprofv3 kernel
  * trace of the same run reports.  avg_ms[8] / launches[8] (may be NULL): average duration and
  * number of launches of { column pass (H), row pass RATIO, column pass (H_t), row pass UPDATE, row
- * pass FWD, row pass INV, Poisson (both kernels), fused Richardson-Lucy loop };
+ * pass FWD, row pass INV, Poisson (both kernels), unused (0) };
  * *frames_per_launch: frames one launch of the RL kernels covers.                        */
 int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, double* avg_ms, double* launches,
                          double* frames_per_launch);

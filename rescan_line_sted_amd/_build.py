@@ -65,7 +65,6 @@ def jobs():
 VARIANTS = {   # study builds: librlsted_<name>.so beside the product library (python -m ..._build --variant NAME)
     'q16': ['-DRL_SPEC_QUANT=1'],     # spectra rounded to IEEE half on their way to memory (BASELINE config 5 study)
     'qbf16': ['-DRL_SPEC_QUANT=2'],   # ... to bfloat16
-    'pk': ['-DRL_PACKED_F32=1'],      # complex float arithmetic on v_pk_*_f32 register pairs (fft_core.hpp: measured, no gain)
 }
 
 

@@ -67,6 +67,7 @@ PROTOTYPES = {
     'rl_gauss_fit': (_i, [_dp, _i, _dp, _c.POINTER(_i)]),
     'rl_gaussian_filter': (_i, [_vp, _dp, _dp, _i, _i, _i, _dp, _c.c_double]),
     'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
+    'rl_psf_generate_line_extras': (_i, [_vp, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp]),
     'rl_rotate_psf': (_i, [_vp, _dp, _dp, _i, _i, _c.c_double]),
     'rl_psf_report': (_i, [_vp, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _dp, _dp]),
     'rl_psf_report_batch': (_i, [_vp, _i, _dp, _dp, _c.POINTER(_dp)]),
@@ -330,8 +331,7 @@ class DeconvPlan:
 
     KERNEL_NAMES = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'poisson')
 
-    CYCLE_KERNELS = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'rowpass_INV',
-                     'poisson', 'rl_fused')
+    CYCLE_KERNELS = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE', 'rowpass_FWD', 'rowpass_INV', 'poisson')
 
     def time_cycle(self, k, rng=RNG_PHILOX, seed=0):
         """rl_deconv_time_cycle: {kernel: (average ms per launch, launches)} of one whole cycle measured with

@@ -245,6 +245,37 @@ hipError_t aux_split_real(int dtype, const void* z, size_t n, void* re, double* 
     return hipGetLastError();
 }
 
+// H_t(ones) without a transform (line_sted_tools.py:589-592): the 'same' convolution of an image of ones with a PSF is
+// the sum of the PSF over the rectangle of taps that still meet the image,
+//     conv(1, p)[i][j] = sum over a in [i + cy - ny + 1, i + cy], b in [j + cx - nx + 1, j + cx] (inside the PSF) of p[a][b],
+// i.e. four reads of the PSF's float64 integral image I[a][b] = sum_{a' < a, b' < b} p[a'][b'] per view; each view's sum is
+// clamped at 0 as the reference clamps each view's convolution (:587).  Exact to float64 rounding, where the transform path
+// of an f32 plan carries ~2e-7 of white rounding noise -- an error every iteration multiplies into the estimate again.
+template <typename T>
+__global__ void k_box_norm(const double* __restrict__ integ, T* __restrict__ out, int V, int py, int px, int ny, int nx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= nx) return;
+    const int cy = (py - 1) / 2, cx = (px - 1) / 2;
+    const int a0 = max(i + cy - ny + 1, 0), a1 = min(i + cy, py - 1) + 1;
+    const int b0 = max(j + cx - nx + 1, 0), b1 = min(j + cx, px - 1) + 1;
+    double acc = 0.0;
+    if (a1 > a0 && b1 > b0) {
+        for (int v = 0; v < V; ++v) {
+            const double* I = integ + (size_t)v * (py + 1) * (px + 1);
+            const double s = (I[(size_t)a1 * (px + 1) + b1] - I[(size_t)a0 * (px + 1) + b1]) - (I[(size_t)a1 * (px + 1) + b0] - I[(size_t)a0 * (px + 1) + b0]);
+            acc += s > 0.0 ? s : 0.0;
+        }
+    }
+    out[(size_t)i * nx + j] = (T)acc;
+}
+
+hipError_t aux_box_norm(int dtype, const double* integral_dev, void* out, int V, int py, int px, int ny, int nx, hipStream_t s) {
+    const dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny);
+    if (dtype == DT_F32) k_box_norm<float><<<grid, 256, 0, s>>>(integral_dev, (float*)out, V, py, px, ny, nx);
+    else k_box_norm<double><<<grid, 256, 0, s>>>(integral_dev, (double*)out, V, py, px, ny, nx);
+    return hipGetLastError();
+}
+
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s,
                        const unsigned long long* frame_seeds, const unsigned* frame_ids, unsigned V) {
@@ -267,8 +298,8 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
 }
 
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
-                             double* sums, hipStream_t s) {
-    if (target) k_frame_sums<<<(unsigned)frames, 1024, 0, s>>>(src, n, sums);
+                             double* sums, hipStream_t s, bool want_sums) {
+    if (target || want_sums) k_frame_sums<<<(unsigned)frames, 1024, 0, s>>>(src, n, sums);
     const unsigned g = blocks_for(n * frames, 256);
     if (dtype == DT_F32) k_scale_convert<float><<<g, 256, 0, s>>>(src, (float*)dst, n, frames, target, sums);
     else k_scale_convert<double><<<g, 256, 0, s>>>(src, (double*)dst, n, frames, target, sums);

@@ -22,9 +22,13 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
                        const unsigned long long* frame_seeds = nullptr, const unsigned* frame_ids = nullptr, unsigned V = 1);
 // float64 stack [frames][n] (device) -> plan dtype, each frame scaled to sum target[f]
 // (target / sums: device arrays of `frames` doubles; target == nullptr: no scaling)
+// want_sums: fill `sums` even without a target (the caller reads the frames' levels)
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
-                             double* sums, hipStream_t s);
+                             double* sums, hipStream_t s, bool want_sums = false);
 hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s);
 // re[i] = z[i].re for n complex values of `dtype`; stats (device, 2 doubles) <- max |im|, max(|re|, |im|)
 hipError_t aux_split_real(int dtype, const void* z, size_t n, void* re, double* stats, hipStream_t s);
+// out [ny][nx] (plan dtype) = sum_v max(conv_same(ones, psf_v), 0) from the PSFs' float64 integral images
+// integral_dev [V][py+1][px+1] (I[a][b] = sum of psf[a' < a][b' < b]): H_t(ones) to float64 rounding, no transform
+hipError_t aux_box_norm(int dtype, const double* integral_dev, void* out, int V, int py, int px, int ny, int nx, hipStream_t s);
 }  // namespace rl

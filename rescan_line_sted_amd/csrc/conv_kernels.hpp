@@ -25,19 +25,41 @@
 namespace rl {
 
 // a / b.  float: hardware reciprocal (v_rcp_f32, <= 1 ulp) times a -- the f32 plans
-// are specified to 1e-5, an IEEE-exact quotient costs ~10 instructions per element;
+// are specified to 1e-5, an IEEE-exact quotient costs ~10 instructions per element
+// (measured in round 2: it moves the f32 error by < 1 % and costs 1.6 % frames/s);
 // double: exact division.  On the host (emulator) both are plain divisions.
-#ifndef RL_EXACT_DIV
-#define RL_EXACT_DIV 0
-#endif
 RL_HD float rl_div(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !RL_EXACT_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     return a * __builtin_amdgcn_rcpf(b);
 #else
     return a / b;
 #endif
 }
 RL_HD double rl_div(double a, double b) { return a / b; }
+
+// ---------------------------------------------------------------------------
+// "Ratio minus one" (RowParams::sub_one, f32 plans with non-negative PSFs).  The 'same' convolution is linear and
+// zero padded, so  conv(ratio, p) = conv(ones, p) + conv(ratio - 1, p)  exactly, and conv(ones, p) summed over the
+// views IS the normaliser H_t(ones) (ref:589-592; non-negative PSFs: its clamp never acts).  The second half of an
+// iteration then transforms `ratio - 1` -- a residual of the size of the shot noise once the estimate explains the
+// data -- instead of a ratio of order one, and
+//     estimate *= max(1 + sum_v conv(ratio_v - 1, p_v) / norm, 0)        ( = sum_v conv(ratio_v, p_v) / norm, ref:527-530 )
+// The transforms' f32 rounding error is proportional to what they carry: the white ~2e-7 per iteration that H_t's
+// transforms stamped onto the update factor (it is not blurred by any later convolution, so every iteration adds to
+// it) shrinks with the residual.  Same arithmetic count, identical in exact arithmetic; the clamp (ref:587) acts on
+// the view sum, as in the fused-views mode.
+template <typename T>
+RL_HD T rl_ratio(T meas, T e, bool sub_one) { return rl_div(sub_one ? meas - e : meas, e); }
+// a: sum over the views of the back-transformed values -- clamped per view (plain mode) or raw (sub_one)
+template <typename T>
+RL_HD T rl_update_factor(T a, T nrm, bool sub_one) {
+    const T f = rl_div(a, nrm);
+    if (!sub_one) return f;
+    const T g = (T)1 + f;
+    return g > (T)0 ? g : (T)0;
+}
+template <typename T>
+RL_HD T rl_clamp0(T x) { return x > (T)0 ? x : (T)0; }
 
 // ---------------------------------------------------------------------------
 // Storage-precision STUDY builds (BASELINE config 5: "fp32 vs fp16 convolve, tolerance study"):
@@ -64,33 +86,11 @@ RL_HD cx<T> rl_spec_round(cx<T> v, float qscale) {
 }
 
 // ---------------------------------------------------------------------------
-// Layout of a row-transformed spectrum image in global memory (ny rows x pitch columns of
-// complex T, pitch a multiple of 8): plain row-major rows, or -- RL_SPEC_BLOCKED -- blocked as
-// [row pair][8-column block][row parity][8 columns], so that the 2 x 8 elements two consecutive
-// rows contribute to an 8-column tile are one contiguous 128-byte line (f32) and every line a
-// column tile touches is its own (the row kernels work on row pairs and then read / write both
-// halves of the same lines back to back).  Built, tested (emulator and GPU) and measured: the
-// column kernel's fabric reads do not change (1.90 MB per frame either way -- its excess over the
-// 1.21 MB spectrum is psf_hat being re-fetched, not half-used lines) and the path is 1.1 % slower
-// (same-box A/B), so row-major stays the default.
-#ifndef RL_SPEC_BLOCKED
-#define RL_SPEC_BLOCKED 0
-#endif
-RL_HD int spec_rows(int ny) { return RL_SPEC_BLOCKED ? (ny + 1) & ~1 : ny; }
-RL_HD size_t spec_image_elems(int ny, int pitch) { return (size_t)spec_rows(ny) * pitch; }
-RL_HD size_t spec_off(int row, int col, int pitch) {
-#if RL_SPEC_BLOCKED
-    return ((size_t)(row >> 1) * (pitch >> 3) + (col >> 3)) * 16 + ((row & 1) << 3) + (col & 7);
-#else
-    return (size_t)row * pitch + col;
-#endif
-}
-// element offset of column k relative to the start of a row pair's storage (row parity 0):
-// lanes t + 64 it use  spec_pair_lane(t) + it * SPEC_PAIR_STEP64; the odd row is SPEC_ODD_ROW further
-RL_HD size_t spec_pair_off(int pair, int pitch) { return (size_t)pair * 2 * pitch; }
-RL_HD unsigned spec_pair_col(unsigned k) { return RL_SPEC_BLOCKED ? 2 * k - (k & 7) : k; }
-constexpr unsigned SPEC_PAIR_STEP64 = RL_SPEC_BLOCKED ? 128 : 64;   // 64 columns further
-RL_HD unsigned spec_odd_row(int pitch) { return RL_SPEC_BLOCKED ? 8u : (unsigned)pitch; }
+// Layout of a row-transformed spectrum image in global memory: ny rows x pitch columns of complex T, row-major
+// (pitch a multiple of 8).  (A blocked layout -- row pairs x 8-column blocks, one 128-byte line per tile and row
+// pair -- was built and measured in round 1: the column kernel's fabric reads did not change, 1.1 % slower; removed.)
+RL_HD size_t spec_image_elems(int ny, int pitch) { return (size_t)ny * pitch; }
+RL_HD size_t spec_off(int row, int col, int pitch) { return (size_t)row * pitch + col; }
 
 // ------------------------------ column pass --------------------------------
 // For one tile of C spectrum columns: forward FFT along y (rows >= ny are
@@ -588,6 +588,7 @@ struct RowParams {
     // from estimate = 1 (ref:522), whose H(est) is the same for every frame: its V column-transformed
     // spectra are computed once per plan and every frame's ROW_RATIO reads them.
     int in_mod = 0;
+    int sub_one = 0;        // ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE multiplies by max(1 + acc / norm, 0): see rl_ratio
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
@@ -672,10 +673,11 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             run_passes<Cfg, true, 0, false>(v, tl, t, view_lds, p.tw, sync);
             rl_stamp(sync, 2);
             if constexpr (MULTI && !ONEV) {
+                const bool raw = MODE == ROW_UPDATE && p.sub_one;   // residual views are summed as they are, the sum is clamped
 #pragma unroll
                 for (int s = 0; s < NB * R; ++s) {
-                    acc[s].re += v[s].re > (T)0 ? v[s].re : (T)0;
-                    acc[s].im += v[s].im > (T)0 ? v[s].im : (T)0;
+                    acc[s].re += raw ? v[s].re : rl_clamp0(v[s].re);
+                    acc[s].im += raw ? v[s].im : rl_clamp0(v[s].im);
                 }
             }
         }
@@ -724,19 +726,20 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (inx && ok0) dst[(size_t)r0 * p.nx + i] = v[s].re > (T)0 ? v[s].re : (T)0;
                 if (inx && ok1) dst[(size_t)r1 * p.nx + i] = v[s].im > (T)0 ? v[s].im : (T)0;
             } else if constexpr (MODE == ROW_RATIO) {
-                if (inx && ok0) z.re = rl_div(pre[PREFETCH ? s : 0].re, v[s].re > (T)0 ? v[s].re : (T)0);
-                if (inx && ok1) z.im = rl_div(pre[PREFETCH ? s : 0].im, v[s].im > (T)0 ? v[s].im : (T)0);
+                if (inx && ok0) z.re = rl_ratio(pre[PREFETCH ? s : 0].re, rl_clamp0(v[s].re), p.sub_one != 0);
+                if (inx && ok1) z.im = rl_ratio(pre[PREFETCH ? s : 0].im, rl_clamp0(v[s].im), p.sub_one != 0);
             } else if constexpr (MODE == ROW_UPDATE) {
                 T* __restrict__ est = p.dst + (size_t)by * rimg;
-                const cx<T> a = ONEV ? mk<T>(v[s].re > (T)0 ? v[s].re : (T)0, v[s].im > (T)0 ? v[s].im : (T)0) : acc[ONEV ? 0 : s];
+                const bool sub = p.sub_one != 0;
+                const cx<T> a = ONEV ? (sub ? v[s] : mk<T>(rl_clamp0(v[s].re), rl_clamp0(v[s].im))) : acc[ONEV ? 0 : s];
                 if (inx && ok0) {
                     const size_t o = (size_t)r0 * p.nx + i;
-                    z.re = pre[PREFETCH ? s : 0].re * rl_div(a.re, nrm[NORMED ? s : 0].re);
+                    z.re = pre[PREFETCH ? s : 0].re * rl_update_factor(a.re, nrm[NORMED ? s : 0].re, sub);
                     est[o] = z.re;
                 }
                 if (inx && ok1) {
                     const size_t o = (size_t)r1 * p.nx + i;
-                    z.im = pre[PREFETCH ? s : 0].im * rl_div(a.im, nrm[NORMED ? s : 0].im);
+                    z.im = pre[PREFETCH ? s : 0].im * rl_update_factor(a.im, nrm[NORMED ? s : 0].im, sub);
                     est[o] = z.im;
                 }
             } else if constexpr (MODE == ROW_ADJ) {
@@ -787,193 +790,17 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     }
 }
 
-// ============================================================================
-// Streaming variants of the Richardson-Lucy kernels (wave-private transform
-// lengths, one view): persistent workgroups walk the work items, the twiddle
-// table lives in LDS, and the operands of item i+1 are requested while item i
-// is being transformed.
-//
-// Why: stamps (tools/stamp_probe.hip) show a wave of the tiled kernels idle for
-// ~30 % of its life in the initial HBM round trip, and the occupancy (4-5 waves
-// per SIMD) cannot cover it.  Twiddles must leave global memory for this to work:
-// vmcnt retires in order, so waiting for a twiddle load issued behind the
-// prefetch would wait for the prefetch too.
-// ============================================================================
-template <class Cfg>
-struct StreamTw {
-    static constexpr int COUNT = PassTw<Cfg, false, 0>::TOTAL;   // complex entries, both directions
-};
-
-// Opaque to the optimiser: keeps loop-invariant LDS twiddle reads (and the address
-// arithmetic behind them) inside the item loop instead of in ~60 hoisted registers.
-RL_HD int stream_launder(int x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(x));
-#endif
-    return x;
-}
-// Same for a per-lane value (the thread index): everything derived from it -- a dozen 64-bit
-// addresses per stage -- is then recomputed per item (a few VALU ops) instead of living in
-// registers across the whole loop body.
-RL_HD int stream_launder_lane(int x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(x));
-#endif
-    return x;
-}
-
-template <typename P>
-RL_HD const P* stream_launder_ptr(const P* x) {   // a wave-uniform pointer, same purpose
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(x));
-#endif
-    return x;
-}
-
-// Work item order of a persistent grid.  Workgroups are dealt round-robin over the 8 XCDs
-// (wg % 8); each XCD gets a contiguous range of items so that neighbouring tiles -- which share
-// 128-B lines -- meet in one L2.  Any order is correct.
-struct StreamOrder {
-    int total, nwg, wg;
-    bool xcd;
-    RL_HD StreamOrder(int total_, int nwg_, int wg_) : total(total_), nwg(nwg_), wg(wg_), xcd(total_ % 8 == 0 && nwg_ % 8 == 0) {}
-    RL_HD int item(int k) const {   // k-th item of this workgroup, or -1
-        if (xcd) {
-            const int per = total / 8, idx = wg / 8 + k * (nwg / 8);
-            return idx < per ? (wg % 8) * per + idx : -1;
-        }
-        const long lin = (long)wg + (long)k * nwg;
-        return lin < total ? (int)lin : -1;
-    }
-};
-
-// Column pass, COL_PER_IMAGE semantics, one workgroup of C waves per tile of C spectrum columns.
-template <class Cfg, int C, typename T, class Sync>
-RL_HD void colstream_body(const ColParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
-    static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
-    constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value;
-    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
-    constexpr int NT = 64 * C;
-    static_assert((L * C) % NT == 0, "tile must divide evenly over the workgroup");
-    constexpr int NLD = (L * C) / NT;
-    using FL = PassInfo<Cfg, false, NP - 1>;
-    using IL = PassInfo<Cfg, true, NP - 1>;
-    static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
-    const int w = tid / 64, lane = tid % 64;
-    const size_t img = spec_image_elems(p.ny, p.pitch);
-    LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
-
-    for (int i = tid; i < StreamTw<Cfg>::COUNT; i += NT) lds[C * LP + i] = p.tw[i];
-
-    const int tiles = (p.kx + C - 1) / C;
-    const StreamOrder order(p.images * tiles, nwg, wg);
-    cx<T> x[NLD];
-    // tile element e = tid + it*NT  <->  (row = e / C, column c = e % C)
-    auto request = [&](int lin, int tid) {
-        const int by = lin / tiles, col0 = (lin % tiles) * C;
-        const int frame = by / p.V, view = by % p.V;
-        const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
-        // Unconditional loads from clamped (always valid) addresses, zero selected at the use:
-        // a load under a lane-dependent branch makes every later counted s_waitcnt vmcnt(N)
-        // collapse to vmcnt(0), which would drain the prefetch at its first neighbour's use.
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const int row = e / C, c = e % C;
-            const int rr = row < p.ny ? row : p.ny - 1, cc = col0 + c < p.pitch ? col0 + c : p.pitch - 1;
-            x[it] = in[spec_off(rr, cc, p.pitch)];   // zero selected where it is consumed, not here:
-        }                                            // a select right behind the load would wait for it
-    };
-    int lin = order.item(0);
-    if (lin >= 0) request(lin, tid);
-    sync.wg();   // twiddles are in LDS
-    const int tid0 = tid;
-    for (int k = 0; lin >= 0; ++k) {
-        const cx<T>* tw = lds + stream_launder(C * LP);
-        const int tid = stream_launder_lane(tid0), w = tid / 64, lane = tid % 64;
-        LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
-        const int by = lin / tiles, col0 = (lin % tiles) * C, col = col0 + w;
-        const bool colok = col < p.kx;
-        const int view = by % p.V;
-        rl_stamp(sync, 0);
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const bool ok = e / C < p.ny && col0 + e % C < p.kx;
-            lds[(e % C) * LP + view_lds.nat(e / C)] = mk<T>(ok ? x[it].re : (T)0, ok ? x[it].im : (T)0);
-        }
-        rl_stamp(sync, 1);
-        sync.wg();
-        rl_stamp(sync, 2);
-        const int next = order.item(k + 1);
-        if (colok) {
-            cx<T> v[VMAX];
-            cx<T> tl = mk<T>((T)0, (T)0);
-            run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw, sync);
-            rl_stamp(sync, 3);
-            {   // v, tl *= psf_hat[view] column (register layout of the last forward pass)
-                const cx<T>* __restrict__ ph = p.psf_hat + ((size_t)view * p.kx + col) * L;
-#pragma unroll
-                for (int nb = 0; nb < FL::NBM; ++nb) {
-                    const int j = lane + nb * 64;
-                    if (j < FL::NBF) {
-#pragma unroll
-                        for (int r = 0; r < FL::R; ++r) v[nb * FL::R + r] = cmul(v[nb * FL::R + r], ph[j + r * FL::NBF]);
-                    }
-                }
-                if constexpr (FL::TAIL) tl = cmul(tl, ph[(64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF]);
-            }
-            rl_stamp(sync, 4);
-            request(next >= 0 ? next : lin, tid);   // in flight during the inverse transform and the tile store
-            run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw, sync);
-            sync.wave();   // last pass' LDS reads are done before the column is overwritten
-#pragma unroll
-            for (int nb = 0; nb < IL::NB; ++nb) {
-                const int j = lane + nb * 64;
-                if (j < IL::NBF) {
-#pragma unroll
-                    for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
-                }
-            }
-        } else {
-            request(next >= 0 ? next : lin, tid);
-        }
-        rl_stamp(sync, 5);
-        sync.wg();
-        rl_stamp(sync, 6);
-        {
-            cx<T>* __restrict__ out = p.out + (size_t)by * img;
-#pragma unroll
-            for (int it = 0; it < NLD; ++it) {
-                const int e = tid + it * NT;
-                const int row = e / C, c = e % C;
-                if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(row)], p.qscale);
-            }
-        }
-        rl_stamp(sync, 7);
-        lin = next;
-        if (lin >= 0) sync.wg();   // the tile is read out before the next one is written
-    }
-}
-
-// Row pass, ROW_RATIO or ROW_UPDATE with one view; every wave walks its own row pairs
-// (no workgroup barrier after the twiddle copy).
+// ---------------------------------------------------------------------------------------------
+// Lean single-view row kernels (ROW_RATIO, ROW_UPDATE with one view; wave-private lengths): one row pair per wave.
 //
 // Addressing: the row pair is a property of the wave, so all bases are scalar (rl_uniform) and a
 // lane adds its own small offset: loads and stores are `scalar base + lane offset + immediate`.
 // Loads are unconditional and unclamped: lanes past the end of a row read the following bytes
 // (the plan allocates RL_STREAM_SLACK bytes behind every buffer for the very last row) and the
 // values are discarded where they would be used.  A load under a lane-dependent branch would make
-// every later counted `s_waitcnt vmcnt(N)` collapse to vmcnt(0) and drain the prefetch.
-#ifndef RL_STREAM_LAUNDER_LDS
-#define RL_STREAM_LAUNDER_LDS 1   // 1: LDS lane addresses are recomputed per item (fewer registers, more VALU)
-#endif
-#ifndef RL_LEAN_EST_LATE
-#define RL_LEAN_EST_LATE 0
-#endif
-#ifndef RL_LEAN_NRM_EARLY
-#define RL_LEAN_NRM_EARLY 0   // tiled lean ROW_UPDATE: normaliser loads behind the inverse transform (fewer registers)
-#endif
+// every later counted `s_waitcnt vmcnt(N)` collapse to vmcnt(0).
+// (Rounds 1-2 also carried persistent, prefetching "streaming" forms of these kernels and of the column kernel:
+// whole-batch launches 8-15 % faster, a tie inside the sliced two-stream loop -- DESIGN.md section 4 -- removed.)
 constexpr size_t RL_STREAM_SLACK = 16384;   // >= (L - nx) elements of any dtype for the wave-private lengths
 
 // The two half spectra of one row pair: lanes t + 64*it of rows r0 (A) and r0 + 1 (B; row r0
@@ -985,25 +812,21 @@ struct RowSpectra {
     template <class Sync>
     RL_HD void request(const RowParams<T>& p, int by, int r0, unsigned t, Sync& sync) {
         const cx<T>* __restrict__ sa = p.spec_in + (size_t)(p.in_mod > 0 ? by % p.in_mod : by) * spec_image_elems(p.ny, p.pitch) +
-                                       spec_pair_off(r0 >> 1, p.pitch);
-        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? spec_odd_row(p.pitch) : 0u);
-        const unsigned lane = spec_pair_col(t);
+                                       (size_t)r0 * p.pitch;
+        const cx<T>* __restrict__ sb = sa + (r0 + 1 < p.ny ? (unsigned)p.pitch : 0u);
 #pragma unroll
         for (int it = 0; it < NPK; ++it) {
-            A[it] = rl_ldg(sync, sa + (lane + it * SPEC_PAIR_STEP64));
-            B[it] = rl_ldg(sync, sb + (lane + it * SPEC_PAIR_STEP64));
+            A[it] = rl_ldg(sync, sa + (t + it * 64));
+            B[it] = rl_ldg(sync, sb + (t + it * 64));
         }
     }
 };
 
 // One row pair of ROW_RATIO / ROW_UPDATE (single view) for a wave: spectra `in` (already
 // requested) -> pack -> inverse -> pointwise -> forward -> split -> store.  by, r0: image and first
-// row (wave uniform); t: lane; tl_: lane index used for LDS addressing; tw: twiddle table (global
-// memory or LDS); `after_pack` runs once `in` has been consumed (the streaming body requests the
-// next item's spectra there).
-template <class Cfg, int MODE, bool NRM_EARLY, typename T, class View, class Sync, class AfterPack>
-RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, RowSpectra<Cfg, T>& in, View view_lds,
-                    const cx<T>* tw, Sync& sync, AfterPack&& after_pack) {
+// row (wave uniform); t: lane; tw: twiddle table.
+template <class Cfg, int MODE, typename T, class View, class Sync>
+RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectra<Cfg, T>& in, View view_lds, const cx<T>* tw, Sync& sync) {
     static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "RL modes only");
     constexpr int NP = Cfg::NP, L = Cfg::L;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
@@ -1015,39 +838,22 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
     constexpr int NPK = RowSpectra<Cfg, T>::NPK;
     const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
+    const int tl_ = (int)t;
     const int r1 = r0 + 1;
     const bool ok1 = r1 < p.ny;
     rl_stamp(sync, 0);
-    // operands of the pointwise stage: measurement (ROW_RATIO) / current estimate (ROW_UPDATE)
+    // operands of the pointwise stage, requested ahead of the inverse transform: measurement (ROW_RATIO) / current estimate (ROW_UPDATE)
     cx<T> pre[NB * R];
     T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * p.nx;
     T* __restrict__ const est1 = est0 + (ok1 ? p.nx : 0);
-    auto request_pre = [&] {
+    {
         const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * p.nx : est0;
         const T* __restrict__ s1 = s0 + (ok1 ? p.nx : 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < R; ++r) pre[nb * R + r] = mk<T>(s0[t + (nb * 64 + r * NBF)], s1[t + (nb * 64 + r * NBF)]);
-    };
-    // ROW_UPDATE without NRM_EARLY requests the estimate behind the inverse transform as well
-    // (RL_LEAN_EST_LATE): 36 fewer live registers through the transform buy a fifth wave per SIMD.
-    constexpr bool PRE_LATE = MODE == ROW_UPDATE && !NRM_EARLY && RL_LEAN_EST_LATE;
-    if constexpr (!PRE_LATE) request_pre();
-    // normaliser values (ROW_UPDATE): all of them requested before the first store of the pointwise
-    // stage (see rowpass_body).  NRM_EARLY: together with the estimate, ahead of the inverse
-    // transform, so the pointwise stage never waits for L2 -- at the price of NB*R more live
-    // registers through the transform; otherwise right behind it.
-    cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
-    auto request_norm = [&] {
-        const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
-        const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
-    };
-    if constexpr (MODE == ROW_UPDATE && NRM_EARLY) request_norm();
+    }
     // pack the two half spectra into one Hermitian-free complex row
     fft_sync<Cfg>(sync);   // LDS free
 #pragma unroll
@@ -1059,15 +865,23 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
             if (kk > 0 && kk < L / 2) view_lds.at(L - kk) = mk<T>(a.re + b.im, b.re - a.im);
         }
     }
-    after_pack();
     fft_sync<Cfg>(sync);
     rl_stamp(sync, 1);
     cx<T> v[VMAX];
     cx<T> tl = mk<T>((T)0, (T)0);
     run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
     rl_stamp(sync, 2);
-    if constexpr (PRE_LATE) request_pre();
-    if constexpr (MODE == ROW_UPDATE && !NRM_EARLY) request_norm();
+    // normaliser values (ROW_UPDATE): all of them requested before the first store of the pointwise stage (see
+    // rowpass_body), behind the inverse transform (ahead of it they cost NB*R live registers through the transform)
+    cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
+    if constexpr (MODE == ROW_UPDATE) {
+        const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
+        const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int j = (int)t + nb * 64;
@@ -1077,13 +891,13 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
             const int i = j + r * NBF;
             const bool inx = (j < NBF) && (i < p.nx);
             cx<T> z = mk<T>((T)0, (T)0);
-            const T e0 = v[s].re > (T)0 ? v[s].re : (T)0, e1 = v[s].im > (T)0 ? v[s].im : (T)0;
+            const bool sub = p.sub_one != 0;
             if constexpr (MODE == ROW_RATIO) {
-                z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
-                z.im = inx && ok1 ? rl_div(pre[s].im, e1) : (T)0;
+                z.re = inx ? rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub) : (T)0;
+                z.im = inx && ok1 ? rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub) : (T)0;
             } else {
-                z.re = inx ? pre[s].re * rl_div(e0, nrm[s].re) : (T)0;
-                z.im = inx && ok1 ? pre[s].im * rl_div(e1, nrm[s].im) : (T)0;
+                z.re = inx ? pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s].re, sub) : (T)0;
+                z.im = inx && ok1 ? pre[s].im * rl_update_factor(sub ? v[s].im : rl_clamp0(v[s].im), nrm[s].im, sub) : (T)0;
                 if (inx) est0[t + (nb * 64 + r * NBF)] = z.re;
                 if (inx && ok1) est1[t + (nb * 64 + r * NBF)] = z.im;
             }
@@ -1105,56 +919,27 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int tl_, int by, int r0, 
         }
     }
     fft_sync<Cfg>(sync);
-    cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + spec_pair_off(r0 >> 1, p.pitch);
-    cx<T>* __restrict__ so1 = so0 + spec_odd_row(p.pitch);
-    const unsigned lane_so = spec_pair_col(t);
+    cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
+    cx<T>* __restrict__ so1 = so0 + p.pitch;
 #pragma unroll
     for (int it = 0; it < NPK; ++it) {
         const int kk = tl_ + it * 64;
         if (kk <= L / 2) {
             const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
-            so0[lane_so + it * SPEC_PAIR_STEP64] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
-            if (ok1) so1[lane_so + it * SPEC_PAIR_STEP64] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
+            so0[t + it * 64] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
+            if (ok1) so1[t + it * 64] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
         }
     }
     rl_stamp(sync, 5);
 }
 
-template <class Cfg, int Q, int MODE, typename T, class Sync>
-RL_HD void rowstream_body(const RowParams<T>& p, int tid, int wg, int nwg, cx<T>* lds, Sync& sync) {
-    static_assert(Cfg::T == 64, "streaming bodies need wave-private transforms");
-    constexpr int LP = LdsSlots<Cfg>::value;
-    static_assert((size_t)Cfg::L * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");   // overrun < L elements
-    const int q = rl_uniform(tid / 64);
-    const unsigned t = (unsigned)(tid % 64);
-    LdsView<T, 1, LdsGather<Cfg::L>::value> view_lds{lds + q * LP};
-
-    for (int i = tid; i < StreamTw<Cfg>::COUNT; i += 64 * Q) lds[Q * LP + i] = p.tw[i];
-
-    const int pairs = (p.ny + 1) / 2;
-    const int total = p.frames * pairs, stride = nwg * Q;
-    RowSpectra<Cfg, T> in;
-    int item = wg * Q + q;
-    if (item < total) in.request(p, item / pairs, 2 * (item % pairs), t, sync);
-    sync.wg();   // twiddles are in LDS; from here on the waves never meet again
-    for (; item < total; item += stride) {
-        const cx<T>* tw = lds + stream_launder(Q * LP);
-        const int tl_ = RL_STREAM_LAUNDER_LDS ? stream_launder_lane((int)t) : (int)t;   // lane index for LDS addressing
-        // the next item's spectra land while this one is transformed; unconditional (the last item
-        // re-requests itself) so that the waits of the pointwise stage can count past the loads
-        const int next = item + stride < total ? item + stride : item;
-        row_item<Cfg, MODE, true>(p, t, tl_, item / pairs, 2 * (item % pairs), in, view_lds, tw, sync,
-                            [&] { in.request(p, next / pairs, 2 * (next % pairs), t, sync); });
-    }
-}
-
-// Tiled flavour of the same item code: one row pair per wave, Q waves per workgroup, grid
-// (ceil(pairs / Q), images); twiddles from global memory (L1).  Replaces rowpass_body for the
-// single-view RL modes of the wave-private lengths: scalar row bases and unconditional loads
-// save ~15 % of its VALU instructions and all of its per-load exec branches.
+// One row pair per wave, Q waves per workgroup, grid (ceil(pairs / Q), images); twiddles from global memory (L1).
+// Replaces rowpass_body for the single-view RL modes of the wave-private lengths: scalar row bases and unconditional
+// loads save ~15 % of its VALU instructions and all of its per-load exec branches.
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "lean row body needs wave-private transforms");
+    static_assert((size_t)Cfg::L * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");   // overrun < L elements
     constexpr int LP = LdsSlots<Cfg>::value;
     const int q = rl_uniform(tid / 64);
     const unsigned t = (unsigned)(tid % 64);
@@ -1162,7 +947,7 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     if (r0 >= p.ny) return;   // whole wave; the wave-private row kernels have no workgroup barrier
     RowSpectra<Cfg, T> in;
     in.request(p, by, r0, t, sync);
-    row_item<Cfg, MODE, RL_LEAN_NRM_EARLY != 0>(p, t, (int)t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync, [] {});
+    row_item<Cfg, MODE>(p, t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync);
 }
 
 
@@ -1186,7 +971,6 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 template <class Cfg, int Q, int MODE, typename T, class Sync>
 RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64 || Q == 1, "one transform per wave, or one (workgroup-synchronous) transform per workgroup");
-    static_assert(!RL_SPEC_BLOCKED, "row-major spectra only");
     static_assert(MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE, "pair modes");
     constexpr int NP = Cfg::NP, L = Cfg::L, TT = Cfg::T, LP = LdsSlots<Cfg>::value, VMAX = CfgRegs<Cfg>::VMAX;
     using I0 = PassInfo<Cfg, true, 0>;        // spectrum side, on the way in
@@ -1261,13 +1045,13 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         if constexpr (MODE == ROW_FWD) {
             z = mk<T>(pre[s].re, okb ? pre[s].im : (T)0);
         } else {
-            const T e0 = v[s].re > (T)0 ? v[s].re : (T)0, e1 = v[s].im > (T)0 ? v[s].im : (T)0;
+            const bool sub = p.sub_one != 0;
             if constexpr (MODE == ROW_RATIO) {
-                z.re = inx ? rl_div(pre[s].re, e0) : (T)0;
-                z.im = inx && okb ? rl_div(pre[s].im, e1) : (T)0;
+                z.re = inx ? rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub) : (T)0;
+                z.im = inx && okb ? rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub) : (T)0;
             } else {
-                z.re = inx ? pre[s].re * rl_div(e0, nrm[s]) : (T)0;
-                z.im = inx && okb ? pre[s].im * rl_div(e1, nrm[s]) : (T)0;
+                z.re = inx ? pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s], sub) : (T)0;
+                z.im = inx && okb ? pre[s].im * rl_update_factor(sub ? v[s].im : rl_clamp0(v[s].im), nrm[s], sub) : (T)0;
                 if (inx) p.dst[ra + i] = z.re;
                 if (inx && okb) p.dst[rb + i] = z.im;
             }

@@ -176,27 +176,12 @@ struct OuterCol<2304> {
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
     static constexpr bool MULTI = RL_OUTER_MULTI != 0;   // COL_H_MULTI / COL_HT_SUM kernels (two M x 10 register sets)
 };
-// 1152 = 2 x 576 and 4608 = 8 x 576 on the same body: 2 x 10 / 8 x 10 complex values wait in registers.
-// Measured (us per 512^2-equivalent frame, column kernel alone; whole 20-iteration loop):
-//   4608: 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames: ON.
-//   1152: 1.32 -> 1.14 alone at 4 waves per SIMD (1.39 at 5, 1.46 at 6, spilling), but the 1024^2 loop does not
-//         follow (36.1 ms per 64 frames before, 35.8 / 38.7 / 40.9 at 5 / 4 / 6): OFF, the (8,9,16) x 144 kernel stays.
-#ifndef RL_OUTER_1152
-#define RL_OUTER_1152 0
-#endif
+// 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
+// column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
+// (1152 = 2 x 576 was built too: 1.32 -> 1.14 us alone, no gain in the 1024^2 loop; the (8,9,16) x 144 kernel stays.)
 #ifndef RL_OUTER_4608
 #define RL_OUTER_4608 1
 #endif
-#ifndef RL_OUTER_1152_MIN_WAVES
-#define RL_OUTER_1152_MIN_WAVES 5
-#endif
-template <>
-struct OuterCol<1152> {
-    static constexpr bool value = RL_OUTER_1152 != 0;
-    using Core = typename CfgFor<576>::Cfg;
-    static constexpr int M = 2, C = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
-    static constexpr bool MULTI = false;
-};
 template <>
 struct OuterCol<4608> {
     static constexpr bool value = RL_OUTER_4608 != 0;

@@ -50,70 +50,9 @@ RL_HD cx<T> scale(cx<T> a, T s) { return mk<T>(a.re * s, a.im * s); }
 template <bool INV, typename T>
 RL_HD cx<T> rot90(cx<T> a) { return INV ? mk<T>(-a.im, a.re) : mk<T>(a.im, -a.re); }
 
-// ---- packed single precision (gfx950: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on a register pair) ----
-// cx<float> keeps (re, im) in one 2-vector so that a complex add is ONE instruction and a complex multiply two:
-// the swaps and sign flips of complex arithmetic ride on the instructions' op_sel / neg modifiers.  LLVM's SLP
-// vectoriser finds the same pairs from scalar code only at the price of ~200 v_mov shuffles per transform
-// (_build.py keeps it off); written on vectors there is nothing to re-pair.  Members .re / .im stay accessible
-// (anonymous struct in a union) for the pointwise stages.
-// MEASURED (round 2): 24 % fewer VALU instructions per wave (column kernel 953 -> 728, ROW_RATIO 958 -> 738, ROW_UPDATE
-// 994 -> 767) and NO gain: headline 17.5 k frames/s either way, column kernel alone 26.8 -> 29.2 us per 32-frame launch
-// (L = 2304: 341 -> 372 us) -- the kernels move bytes at the memory system's mixed read/write rate and the VALU was never the
-// critical resource.  Rounding differs slightly (other FMA pairings: 7.9e-6 instead of 6.2e-6 against
-// the float64 oracle at K = 20).  Hence OFF by default; `python -m rescan_line_sted_amd._build --variant pk` builds it.
-#ifndef RL_PACKED_F32
-#define RL_PACKED_F32 0
-#endif
-#if defined(__HIPCC__) && RL_PACKED_F32
-typedef float rl_v2f __attribute__((ext_vector_type(2)));
-template <>
-struct cx<float> {
-    union {
-        rl_v2f v;
-        struct {
-            float re, im;
-        };
-    };
-};
-RL_HD cx<float> mkv(rl_v2f v) {
-    cx<float> r;
-    r.v = v;
-    return r;
-}
-RL_HD cx<float> operator+(cx<float> a, cx<float> b) { return mkv(a.v + b.v); }
-RL_HD cx<float> operator-(cx<float> a, cx<float> b) { return mkv(a.v - b.v); }
-RL_HD cx<float> scale(cx<float> a, float s) { return mkv(a.v * s); }
-RL_HD cx<float> cmul(cx<float> a, cx<float> b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const rl_v2f t = a.v.xx * b.v;   // (a.re b.re, a.re b.im)
-    rl_v2f r;                        // (a.im * -b.im + t.x, a.im * b.re + t.y): one lane negated is beyond the compiler's patterns
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a.v), "v"(b.v), "v"(t));
-    return mkv(r);
-#else
-    return mk<float>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
-#endif
-}
-template <bool INV>
-RL_HD cx<float> rot90(cx<float> a) {
-    return mkv(INV ? rl_v2f{-a.v.y, a.v.x} : rl_v2f{a.v.y, -a.v.x});
-}
-// a +- rot90<INV>(b) in one instruction: the swap is op_sel, the single negated lane neg_lo / neg_hi
-template <bool INV>
-RL_HD cx<float> add_rot(cx<float> a, cx<float> b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    rl_v2f r;
-    if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));   // (a.re - b.im, a.im + b.re)
-    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));       // (a.re + b.im, a.im - b.re)
-    return mkv(r);
-#else
-    return INV ? mk<float>(a.re - b.im, a.im + b.re) : mk<float>(a.re + b.im, a.im - b.re);
-#endif
-}
-template <bool INV>
-RL_HD cx<float> sub_rot(cx<float> a, cx<float> b) { return add_rot<!INV>(a, b); }
-// a * (c + i s) for constants: both tap vectors are literals, no run-time sign flip
-RL_HD cx<float> cmul_const(cx<float> a, float c, float s) { return mkv(a.v.xx * rl_v2f{c, s} + a.v.yy * rl_v2f{-s, c}); }
-#endif
+// (Round 2 measured a packed-f32 form of this arithmetic -- cx<float> on a 2-vector, complex multiply = v_pk_mul_f32 + one
+// v_pk_fma_f32 with op_sel / neg modifiers: 24 % fewer VALU instructions per wave in every RL kernel and no gain in
+// time, a packed op costs ~1.6 scalar ops on this part; DESIGN.md section 8.  Removed.)
 template <typename T>
 RL_HD cx<T> cmul_const(cx<T> a, T c, T s) { return mk<T>(a.re * c - a.im * s, a.re * s + a.im * c); }
 template <bool INV, typename T>

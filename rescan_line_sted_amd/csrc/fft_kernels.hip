@@ -7,7 +7,6 @@
 #include "conv_kernels.hpp"
 #include "fft_configs.hpp"
 #include "dev_sync.hpp"
-#include "fused_rl.hpp"
 
 // waves/SIMD requested for the f32 ROW_RATIO kernel (needs <= 96 VGPRs, which it has
 // within 2 registers; the other modes spill under that bound and are left alone)
@@ -16,11 +15,6 @@
 #endif
 #ifndef RL_UPD_MIN_WAVES
 #define RL_UPD_MIN_WAVES 1
-#endif
-// Off: measured neutral on time, and it costs traffic -- with whole images per XCD every XCD's L2 streams
-// the full normaliser (1 MB) instead of the eighth its row groups touch (ROW_UPDATE +0.5 MB/frame).
-#ifndef RL_ROW_XCD_REMAP
-#define RL_ROW_XCD_REMAP 0
 #endif
 #ifndef RL_ROW_LEAN
 #define RL_ROW_LEAN 1
@@ -153,23 +147,9 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
-    // XCD-consistent image placement (pure speed heuristic, as in k_colconv): workgroups are dealt
-    // round-robin over the 8 XCDs, so give each XCD a contiguous range of (image, row group) items --
-    // the same images the column kernel's remap gives it.  A spectrum written by one kernel is then
-    // read by the next one through the same L2 (whose contents survive the kernel boundary:
-    // tools/l2_probe.hip).
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-#if RL_ROW_XCD_REMAP
-    {
-        const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
-        if (total % 8 == 0) {
-            const unsigned lin = by * gx + bx;
-            const unsigned w = (lin % 8) * (total / 8) + lin / 8;
-            bx = w % gx;
-            by = w / gx;
-        }
-    }
-#endif
+    // (An XCD-consistent remap of (image, row group) items like k_colconv's measured neutral on time and cost traffic -- every
+    // XCD's L2 then streams the whole normaliser instead of the eighth its row groups touch: removed.)
+    const unsigned bx = blockIdx.x, by = blockIdx.y;
     // single-view RL modes of the wave-private lengths: the lean item code (scalar row bases,
     // unconditional loads).  RATIO treats every (frame, view) image on its own, so it always qualifies.
     constexpr bool LEAN = RL_ROW_LEAN && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
@@ -177,145 +157,6 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, 
         rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
         rowpass_body<KCfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
-}
-
-// ---- streaming kernels (wave-private lengths): persistent workgroups, twiddles in LDS ----
-#ifndef RL_STREAM_Q32
-#define RL_STREAM_Q32 8
-#endif
-#ifndef RL_STREAM_Q64
-#define RL_STREAM_Q64 4
-#endif
-#ifndef RL_STREAM_ROW_MIN_WAVES
-#define RL_STREAM_ROW_MIN_WAVES 1
-#endif
-#ifndef RL_STREAM_COL_MIN_WAVES
-#define RL_STREAM_COL_MIN_WAVES 1
-#endif
-template <int L, int C, typename T>
-__global__ void __launch_bounds__(64 * C, sizeof(T) == 4 ? RL_STREAM_COL_MIN_WAVES : 1) k_colstream(const ColParams<T> p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    DevSync s;
-    colstream_body<typename ColCfgFor<L>::type, C, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<T>*>(smem), s);
-}
-template <int L, int Q, int MODE, typename T>
-__global__ void __launch_bounds__(64 * Q, sizeof(T) == 4 ? RL_STREAM_ROW_MIN_WAVES : 1) k_rowstream(const RowParams<T> p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    DevSync s;
-    rowstream_body<typename CfgFor<L>::Cfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<cx<T>*>(smem), s);
-}
-
-template <int N, typename T>
-static constexpr size_t stream_lds_bytes() {
-    return ((size_t)N * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>);
-}
-template <int N, typename T>
-static constexpr size_t col_stream_lds_bytes() {
-    return ((size_t)N * LdsSlots<CCfg>::value + StreamTw<CCfg>::COUNT) * sizeof(cx<T>);
-}
-
-// workgroups of `fn` that the device holds at once (0 on error), a multiple of 8 (one share per XCD)
-template <typename F>
-static int resident_workgroups(F* fn, int threads, size_t lds) {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (lds > 65536 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) return 0;
-    const int n = per_cu * prop.multiProcessorCount;
-    return n >= 8 ? n / 8 * 8 : n;
-}
-
-// ---- fused Richardson-Lucy loop (fused_rl.hpp) ----
-#ifndef RL_FUSED_NW
-#define RL_FUSED_NW 8     // waves per workgroup = columns per tile = row pairs per workgroup round
-#endif
-#ifndef RL_FUSED_MIN_WAVES
-#define RL_FUSED_MIN_WAVES 4   // waves per SIMD asked of the register allocator (2 workgroups of 8 waves per CU)
-#endif
-template <int L, int NW, bool ACQ>
-__global__ void __launch_bounds__(64 * NW, RL_FUSED_MIN_WAVES) k_rl_fused(const FusedParams<float> p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using KCfg = typename CfgFor<L>::Cfg;
-    constexpr size_t tile = (size_t)NW * LdsSlots<KCfg>::value * sizeof(cx<float>);
-    fused_rl_body<KCfg, NW, ACQ, float>(p, reinterpret_cast<cx<float>*>(smem), reinterpret_cast<int*>(smem + tile));
-}
-
-template <bool ACQ>
-static hipError_t launch_fused_t(const FusedParams<float>& p, int wgs_per_cu, hipStream_t s, int* grid_out) {
-    if constexpr (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) {
-        constexpr size_t lds = (size_t)RL_FUSED_NW * LdsSlots<Cfg>::value * sizeof(cx<float>) + 16;
-        auto* fn = k_rl_fused<RL_CFG_L, RL_FUSED_NW, ACQ>;
-        static const int resident = resident_workgroups(fn, 64 * RL_FUSED_NW, lds);
-        if (resident < 8) return hipErrorLaunchFailure;
-        int dev = 0, cus = 0;
-        hipError_t e;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        int grid = resident;
-        if (wgs_per_cu > 0 && wgs_per_cu * cus < grid) grid = wgs_per_cu * cus / 8 * 8;
-        if (grid < 8) return hipErrorLaunchFailure;
-        if ((e = hipMemsetAsync(p.ctrl, 0, kFusedCtrlWords * sizeof(unsigned), s)) != hipSuccess) return e;
-        rl_launch(fn, dim3((unsigned)grid), dim3(64 * RL_FUSED_NW), lds, s, p);
-        if (grid_out) *grid_out = grid;
-        return hipGetLastError();
-    } else {
-        return hipErrorInvalidValue;
-    }
-}
-static hipError_t launch_fused(const void* params, int wgs_per_cu, int acquire, hipStream_t s, int* grid_out) {
-    const FusedParams<float>& p = *static_cast<const FusedParams<float>*>(params);
-    return acquire ? launch_fused_t<true>(p, wgs_per_cu, s, grid_out) : launch_fused_t<false>(p, wgs_per_cu, s, grid_out);
-}
-
-template <int C, typename T>
-static hipError_t launch_col_stream_t(const void* params, hipStream_t s) {
-    if constexpr (WavePrivate<CCfg>::value) {
-        const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
-        constexpr size_t lds = col_stream_lds_bytes<C, T>();
-        static const int resident = resident_workgroups(k_colstream<RL_CFG_L, C, T>, 64 * C, lds);
-        if (resident < 1) return hipErrorLaunchFailure;
-        const long total = (long)p.images * ((p.kx + C - 1) / C);
-        if (total < 1) return hipSuccess;
-        long nwg = total < resident ? total : resident;
-        if (nwg >= 8 && total % 8 == 0) nwg = nwg / 8 * 8;
-        rl_launch(k_colstream<RL_CFG_L, C, T>, dim3((unsigned)nwg), dim3(64 * C), lds, s, p);
-        return hipGetLastError();
-    } else {
-        return hipErrorInvalidValue;
-    }
-}
-
-template <int Q, int MODE, typename T>
-static hipError_t launch_row_stream_m(const void* params, hipStream_t s) {
-    const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
-    constexpr size_t lds = stream_lds_bytes<Q, T>();
-    static const int resident = resident_workgroups(k_rowstream<RL_CFG_L, Q, MODE, T>, 64 * Q, lds);
-    if (resident < 1) return hipErrorLaunchFailure;
-    const long total = (long)p.frames * ((p.ny + 1) / 2);
-    if (total < 1) return hipSuccess;
-    const long need = (total + Q - 1) / Q;
-    rl_launch(k_rowstream<RL_CFG_L, Q, MODE, T>, dim3((unsigned)(need < resident ? need : resident)), dim3(64 * Q), lds, s, p);
-    return hipGetLastError();
-}
-
-template <int Q, typename T>
-static hipError_t launch_row_stream_t(int mode, const void* params, hipStream_t s) {
-    if constexpr (WavePrivate<Cfg>::value) {
-        if (mode == ROW_RATIO) return launch_row_stream_m<Q, ROW_RATIO, T>(params, s);
-        if (mode == ROW_UPDATE) return launch_row_stream_m<Q, ROW_UPDATE, T>(params, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-static hipError_t launch_col_stream(int dtype, const void* params, hipStream_t s) {
-    return dtype == DT_F32 ? launch_col_stream_t<kC32, float>(params, s) : launch_col_stream_t<kC64, double>(params, s);
-}
-static hipError_t launch_row_stream(int dtype, int mode, const void* params, hipStream_t s) {
-    return dtype == DT_F32 ? launch_row_stream_t<RL_STREAM_Q32, float>(mode, params, s)
-                           : launch_row_stream_t<RL_STREAM_Q64, double>(mode, params, s);
 }
 
 template <int C, typename T>
@@ -522,9 +363,6 @@ const KernelTable* RL_TABLE_FN() {
                                   PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
                                   {OuterTw<RL_CFG_L, OUTER>::count, PassTw<CCfg, false, 0>::TOTAL},
                                   {OuterTw<RL_CFG_L, OUTER>::fill, fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,
-                                  WavePrivate<CCfg>::value ? launch_col_stream : nullptr,
-                                  WavePrivate<Cfg>::value ? launch_row_stream : nullptr,
-                                  (WavePrivate<Cfg>::value && WavePrivate<CCfg>::value) ? launch_fused : nullptr,
                                   kPairRows ? launch_row_pair : nullptr};
     return &t;
 }

@@ -32,17 +32,6 @@ struct KernelTable {
     hipError_t (*launch_row)(int dtype, int mode, const void* params, unsigned grid_x, unsigned grid_y, hipStream_t s);
     // one-time attribute setup (dynamic LDS above the default limit)
     hipError_t (*prepare)(void);
-    // Streaming (persistent, prefetching) Richardson-Lucy kernels for one view; nullptr when the
-    // length has none (transforms that are not wave private).  The grid is sized inside from the
-    // occupancy of the kernel; params carry the image count (ColParams::images / RowParams::frames).
-    hipError_t (*launch_col_stream)(int dtype, const void* params, hipStream_t s);
-    hipError_t (*launch_row_stream)(int dtype, int mode, const void* params, hipStream_t s);
-    // Fused Richardson-Lucy loop (fused_rl.hpp; f32, one view, wave-private lengths, ly == lx): one
-    // persistent launch runs all iterations of all frames.  params: FusedParams<float>; the control
-    // block is zeroed on the stream first.  wgs_per_cu: requested residency (clamped to what the
-    // occupancy query allows); acquire: 1 = plain loads behind buffer_inv sc1, 0 = sc1 loads.
-    // nullptr when the length has none.
-    hipError_t (*launch_fused)(const void* params, int wgs_per_cu, int acquire, hipStream_t s, int* grid_out);
     // Frame-pair row kernels (conv_kernels.hpp rowpair_body: two frames in one complex image, spectra [ny][L]; modes
     // ROW_FWD / ROW_RATIO / ROW_UPDATE, one view): grid (ceil(ny / Q), pairs), RowParams::frames = frames covered.
     // nullptr when the length's row transform is not wave private.

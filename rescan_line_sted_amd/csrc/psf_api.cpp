@@ -103,6 +103,15 @@ int rl_rotate_psf(rl_ctx* ctx, const double* in, double* out, int ny, int nx, do
 //   scalars_out   [10]: 0 rescan ratio used, 1 ideal (float) ratio, 2-4 area sums of
 //                 excitation / depletion / sted, 5-7 central-row sums of the same,
 //                 8 = 1 if every central-row maximum equals its array maximum (:105-106,120), 9 reserved
+// Host buffers of rl_psf_generate_line_extras for the generate call it wraps (this thread's next one)
+namespace {
+struct LineExtras {
+    double* emission = nullptr;   // [ny][nx]
+    double* unscaled = nullptr;   // [ny][ratio * nx]
+};
+thread_local LineExtras g_line_extras;
+}  // namespace
+
 int rl_psf_generate(rl_ctx* ctx, int psf_type, int ny, int nx, double exc_b, double dep_b, double sigma,
                     int rescan_ratio, double* arrays_out, double* rows_out, double* scalars_out) {
     if (!ctx || !scalars_out) return fail(RL_ERR_INVALID, "NULL argument");
@@ -185,6 +194,18 @@ int rl_psf_generate(rl_ctx* ctx, int psf_type, int ny, int nx, double exc_b, dou
         }
         hipError_t e = psf_rescan(sted + (size_t)cy * nx, L.w, radius, L.ry, L.rx, ny, nx, ratio, L.b0, L.cumu, descan,
                                   rescan, s);
+        const LineExtras extras = g_line_extras;
+        g_line_extras = LineExtras();
+        if (e == hipSuccess && extras.unscaled)   // rescanned_signal_cumu (:266,298): the ring before the roll and the binning
+            e = hipMemcpyAsync(extras.unscaled, L.cumu, (size_t)ratio * n * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && extras.emission) {   // emission_psf = gaussian_filter(point delta, sigma) (:258-260); delta / g / tmp are free by now
+            e = psf_delta(L.delta, ny, nx, 0, s);
+            if (e == hipSuccess) e = psf_blur_axis(L.delta, L.g, 1, ny, nx, 0, L.w, radius, s);
+            if (e == hipSuccess) e = psf_blur_axis(L.g, L.tmp, 1, ny, nx, 1, L.w, radius, s);
+            if (e == hipSuccess) e = psf_blur_axis(L.tmp, L.g, 1, ny, nx, 2, L.w, radius, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(extras.emission, L.g, n * sizeof(double), hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess && (extras.unscaled || extras.emission)) e = hipStreamSynchronize(s);
         if (big) {
             hipError_t e2 = hipStreamSynchronize(s);
             (void)hipFree(big);
@@ -227,6 +248,18 @@ int rl_psf_generate(rl_ctx* ctx, int psf_type, int ny, int nx, double exc_b, dou
     scalars_out[8] = peaks ? 1.0 : 0.0;
     scalars_out[9] = 0.0;
     return RL_OK;
+}
+
+int rl_psf_generate_line_extras(rl_ctx* ctx, int ny, int nx, double exc_b, double dep_b, double sigma, int rescan_ratio,
+                                double* emission_psf_out, double* rescan_unscaled_out) {
+    if (!ctx) return fail(RL_ERR_INVALID, "NULL argument");
+    if (rescan_ratio < 1) return fail(RL_ERR_INVALID, "rescan_ratio must be the ratio a previous rl_psf_generate reported (scalars_out[0])");
+    g_line_extras.emission = emission_psf_out;
+    g_line_extras.unscaled = rescan_unscaled_out;
+    double scalars[10];
+    const int rc = rl_psf_generate(ctx, 1, ny, nx, exc_b, dep_b, sigma, rescan_ratio, nullptr, nullptr, scalars);
+    g_line_extras = LineExtras();
+    return rc;
 }
 
 // psf_report (:75-166) in one call: returns report_out[8] = { resolution_improvement_

@@ -20,7 +20,6 @@
 #include "conv_kernels.hpp"
 #include "kernel_table.hpp"
 #include "ctx.hpp"
-#include "fused_rl.hpp"
 #include "sep_kernels.hpp"
 
 using namespace rl;
@@ -82,6 +81,10 @@ struct rl_deconv {
     // estimate-type / ratio-type spectrum to 2^14 (RLSTED_Q_EXP_EST / RLSTED_Q_EXP_RATIO = log2 of the DC bound)
     float q_est = 1.0f, q_ratio = 1.0f;
     bool ones_shortcut = true; // first iteration reads spec_ones instead of transforming a frame of ones (RLSTED_ONES_SHORTCUT=0: off)
+    // f32 plans (conv_kernels.hpp rl_ratio): the normaliser H_t(ones) from the PSFs' integral images instead of the f32 transform
+    // path (RLSTED_EXACT_NORM=0: off), and -- non-negative PSFs -- the second half of every iteration on `ratio - 1`
+    // (RLSTED_SUB_ONE=0: off).  Both shrink f32 rounding error, neither changes the arithmetic in exact terms.
+    bool exact_norm = false, sub_one = false;
     void* obj = nullptr;       // [B][ny][nx]
     void* noiseless = nullptr; // [B*V][ny][nx]
     void* meas = nullptr;      // [B*V][ny][nx]
@@ -93,10 +96,6 @@ struct rl_deconv {
     // H_t views summed before the inverse transforms (one clamp of the sum instead of one per
     // view, ref:587): default for f32 plans, off for f64 (faithful); RLSTED_FUSE_VIEWS=0/1 overrides
     bool fuse_views = false;
-    // persistent prefetching RL kernels where the length has them; bit mask: 1 column pass,
-    // 2 ROW_RATIO, 4 ROW_UPDATE.  Off by default: measured equal to the tiled kernels inside the
-    // chunked RL loop; RLSTED_STREAM=7 turns them on.
-    int streaming = 0;
     // Slices of the batch are independent: they are iterated on `lanes` HIP streams at once so that
     // the tail of one slice's kernel (the last, partly filled round of workgroups) overlaps another
     // slice's kernels.  RLSTED_LANES=1: one slice after the other on the context's stream.
@@ -106,9 +105,6 @@ struct rl_deconv {
     hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
     hipStream_t active = nullptr;                     // stream the kernel launch helpers use
-    hipStream_t sim_stream = nullptr;                 // run_cycle(): simulation of all slices, ahead of the RL lanes
-    std::vector<hipEvent_t> sim_done;                 // one per slice
-    bool sim_ahead = false;                           // RLSTED_SIM_AHEAD=1 (measured -4 %: see run_slices)
     bool defer_join = false, lanes_open = false;      // rl_deconv_bench_cycles: no lane join between its cycles
     void* slice_ws = nullptr;                         // per-slice Poisson work lists of run_cycle()
     void *key_seeds = nullptr, *key_ids = nullptr;    // per-frame Philox keys of rl_deconv_simulate_keyed
@@ -129,12 +125,40 @@ struct rl_deconv {
     // ---- frame pairs (conv_kernels.hpp rowpair_body; RLSTED_PAIR): two frames ride through one complex image, the
     // Richardson-Lucy loop of a single-view plan then runs on spectra [pairs][ny][lx] -- no Hermitian packing /
     // splitting around the row transforms.  The simulation and the H / H_t calls keep the per-frame layout.
-    bool pair = false;
+    bool pair = false;          // the loop that runs: pair_layout && the batch's partners are of comparable brightness (choose_loop)
+    bool pair_layout = false;   // the plan holds the pair buffers (psf_hat_pair, spec_ones_pair)
+    // A pair's two frames share one complex transform, so f32 rounding error scales with the BRIGHTER partner: a dim frame
+    // next to one 1e5 times brighter would carry ~1e5 times its own error through H.  Frames are paired only while every
+    // pair's levels (sums of the object / measurement images) are within kPairMaxRatio of each other
+    // (RLSTED_PAIR_MAX_RATIO); otherwise the plan runs its per-frame loop, which every pair plan also holds.
+    double pair_max_ratio = 4.0;
+    std::vector<double> obj_level, meas_level;   // per frame (host): sum of the object / of the measurement over its views
+    bool levels_ok(const std::vector<double>& lv) const {
+        if ((int)lv.size() != B) return true;    // nothing known yet
+        for (int f = 0; f + 1 < B; f += 2) {
+            const double lo = std::min(lv[f], lv[f + 1]), hi = std::max(lv[f], lv[f + 1]);
+            if (lo == 0.0 && hi == 0.0) continue;   // two empty frames
+            if (!(lo > 0.0) || !std::isfinite(hi) || hi > pair_max_ratio * lo) return false;
+        }
+        return true;
+    }
+    void choose_loop(const std::vector<double>& lv) {
+        const bool want = pair_layout && levels_ok(lv);
+        if (want != pair) {
+            pair = want;
+            spec_valid = false;   // spec_a holds the other layout's spectra
+        }
+    }
     bool keep_last_spectrum = false;   // RLSTED_KEEP_LAST_SPECTRUM=1: every iteration ends with rowFFT(estimate)
     bool drop_last_spectrum = false;   // set by run_slices for the last iteration of a long run: ROW_UPDATE skips rowFFT(estimate)
     void *psf_hat_pair = nullptr, *psf_hat_pair_re = nullptr;   // psf_hat at full width: [lx][ly] (transposed layout)
     void* spec_ones_pair = nullptr;                              // column-transformed spectrum of a pair of ones frames
-    size_t n_spec_pair() const { return spec_image_elems(ny, lx); }
+    // Row pitch of a pair spectrum (complex elements): lx, or lx + 32 for the long rows (lx >= 1152).  A pitch of exactly lx
+    // makes the row stride (lx * 8 bytes in f32: 18432 / 36864) an EVEN multiple of 256 bytes, and the column kernels' tile
+    // rows -- one 64-byte segment per row -- then fall on a fraction of the memory channels; + 256 bytes makes it an odd
+    // multiple (RLSTED_PAIR_PAD columns).  Worth 2-4 % on the long rows, costs 3 % at lx = 576 (4608-byte rows: left alone).
+    int pair_pitch = 0;
+    size_t n_spec_pair() const { return spec_image_elems(ny, pair_pitch); }
     void* pair_spec(int f0) const { return (char*)spec_a + (size_t)(f0 / 2) * n_spec_pair() * 2 * esize(dtype); }
     // kind: COL_H (pair spectrum -> V images; in place when V == 1), COL_HT_VIEW (V == 1, in place) or COL_HT_FUSED
     // (V images summed in the Fourier domain -> pair spectrum)
@@ -147,7 +171,7 @@ struct rl_deconv {
         p.psf_hat_re = (const T*)psf_hat_pair_re;
         p.qscale = kind == COL_H ? q_est : q_ratio;
         p.tw = (const cx<T>*)twy;
-        p.ny = ny; p.kx = lx; p.pitch = lx; p.V = V;
+        p.ny = ny; p.kx = lx; p.pitch = pair_pitch; p.V = V;
         p.mode = V == 1 ? COL_PER_IMAGE : (kind == COL_H ? COL_H_MULTI : COL_HT_SUM);
         p.in_sb = 1; p.in_sv = 0;
         p.images = pairs; p.order = col_order;
@@ -173,6 +197,7 @@ struct rl_deconv {
     int row_pair_t(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod, int views) {
         RowParams<T> p;
         p.in_mod = in_mod;
+        p.sub_one = sub_one ? 1 : 0;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -181,7 +206,7 @@ struct rl_deconv {
         p.norm = (const T*)nrm;
         p.scale = nullptr;
         p.tw = (const cx<T>*)twx;
-        p.ny = ny; p.nx = nx; p.pitch = lx; p.V = views;
+        p.ny = ny; p.nx = nx; p.pitch = pair_pitch; p.V = views;
         p.frames = frames;
         TimedScope t(this, mode == ROW_RATIO ? TK_RATIO : mode == ROW_UPDATE ? TK_UPDATE : TK_FWD);
         HIP_TRY(tx->launch_row_pair(dtype, mode, &p, (unsigned)((frames + 1) / 2 * views), cur()));
@@ -262,80 +287,9 @@ struct rl_deconv {
         return sep_cols_(SEP_UPDATE_, tmp, nullptr, norm, e, nf);
     }
 
-    // ---- fused Richardson-Lucy loop (fused_rl.hpp): one persistent launch runs the K iterations of all
-    // frames, a frame's spectrum staying in the L2 of the XCD whose team owns it.  f32, one view, in place,
-    // ly == lx on a wave-private length.  Built, parity-tested and measured: it cuts the
-    // fabric traffic of a frame-iteration from 13.7 to 11.2 MB but is latency bound with the one or two frames
-    // an XCD's L2 holds, so it is opt-in: RLSTED_FUSED=1.
-    int fused = 0;                 // 0 off, 1 on where available
-    int fused_team = 32;           // workgroups per team (RLSTED_FUSED_W)
-    int fused_wgs = 2;             // workgroups per CU (RLSTED_FUSED_WGS)
-    int fused_streams = 2;         // frames a team keeps in flight (RLSTED_FUSED_S)
-    int fused_acq = 0;             // 1: plain loads behind buffer_inv sc1 (RLSTED_FUSED_ACQ)
-    bool fused_checked = false;    // the first launch has been validated (teams formed, all frames done)
-    unsigned* fused_ctrl = nullptr;
-    unsigned* fused_status = nullptr;   // pinned host copy of the control block's head
-    int fused_grid = 0;
-    int fused_pending_frames = -1;      // frames the last unchecked launch must report
-    bool fused_available() const {
-        return fused && dtype == RL_F32 && V == 1 && inplace && ly == lx && ty == tx && ty->launch_fused != nullptr;
-    }
-    int fused_launch(int f0, int nf, int k) {
-        if (!fused_ctrl) {
-            HIP_TRY(hipMalloc((void**)&fused_ctrl, kFusedCtrlWords * sizeof(unsigned)));
-            HIP_TRY(hipHostMalloc((void**)&fused_status, FW_TEAM_BASE * sizeof(unsigned)));
-            bytes += kFusedCtrlWords * sizeof(unsigned);
-        }
-        RL_TRY(fused_check());   // the previous launch's report, before its words are reused
-        FusedParams<float> p;
-        p.spec = (cx<float>*)off(spec_a, (size_t)f0 * n_spec() * 2);
-        p.meas = (const float*)off(meas, (size_t)f0 * n_img());
-        p.est = (float*)off(est, (size_t)f0 * n_img());
-        p.norm = (const float*)norm;
-        p.psf_hat = (const cx<float>*)psf_hat;
-        p.twy = (const cx<float>*)twy;
-        p.twx = (const cx<float>*)twx;
-        p.ctrl = fused_ctrl;
-        p.ny = ny; p.nx = nx; p.kx = kx; p.pitch = pitch;
-        p.frames = nf; p.iters = k;
-        p.team_wgs = fused_team;
-        p.streams = fused_streams;
-        p.timeout_us = 1000000u;
-        p.flags = getenv("RLSTED_FUSED_FLAGS") ? (unsigned)atoi(getenv("RLSTED_FUSED_FLAGS")) : 0u;
-        {
-            TimedScope t(this, TK_FUSED);
-            HIP_TRY(ty->launch_fused(&p, fused_wgs, fused_acq, cur(), &fused_grid));
-        }
-        HIP_TRY(hipMemcpyAsync(fused_status, fused_ctrl, FW_TEAM_BASE * sizeof(unsigned), hipMemcpyDeviceToHost, cur()));
-        fused_pending_frames = nf;
-        if (!fused_checked) {   // first launch of this plan: look at its report before anything builds on it
-            HIP_TRY(hipStreamSynchronize(cur()));
-            RL_TRY(fused_check());
-            fused_checked = true;
-        }
-        return RL_OK;
-    }
-    // report of the last fused launch (the stream it ran on must have been synchronised, or the
-    // launch is still pending: then this waits for it)
-    int fused_check() {
-        if (fused_pending_frames < 0) return RL_OK;
-        HIP_TRY(hipDeviceSynchronize());
-        const int want = fused_pending_frames;
-        fused_pending_frames = -1;
-        const unsigned abort_code = fused_status[FW_ABORT], done = fused_status[FW_FRAMES_DONE], teams = fused_status[FW_TEAMS];
-        if (abort_code == 0 && (int)done == want) return RL_OK;
-        std::string xs;
-        for (int x = 0; x < 16; ++x) xs += (x ? "," : "") + std::to_string(fused_status[FW_XCD_COUNT + 32 * x]);
-        return fail(RL_ERR_HIP, "fused Richardson-Lucy kernel: abort code " + std::to_string(abort_code) + ", " +
-                                    std::to_string(done) + " of " + std::to_string(want) + " frames done, " +
-                                    std::to_string(teams) + " teams of " + std::to_string(fused_team) + ", grid " +
-                                    std::to_string(fused_grid) + ", registered " + std::to_string(fused_status[FW_REGISTERED]) +
-                                    ", workgroups per XCD [" + xs + "] (RLSTED_FUSED=0 selects the four-launch iteration)");
-    }
-
     // ---- in-situ kernel timing (rl_deconv_time_cycle): an event pair around every launch of one whole
     // cycle, on the stream the launch goes to, with the slice streams overlapping as in production
-    enum TimedKind { TK_COL_H = 0, TK_RATIO, TK_COL_HT, TK_UPDATE, TK_FWD, TK_INV, TK_POISSON, TK_FUSED, TK_COUNT };
+    enum TimedKind { TK_COL_H = 0, TK_RATIO, TK_COL_HT, TK_UPDATE, TK_FWD, TK_INV, TK_POISSON, TK_COUNT };
     struct TimedLaunch { int kind; hipEvent_t a, b; };
     bool timing = false;
     std::vector<TimedLaunch> timed;
@@ -407,10 +361,7 @@ struct rl_deconv {
         p.order = col_order;
         {
             TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
-            if ((streaming & 1) && p.mode == COL_PER_IMAGE && ty->launch_col_stream)
-                HIP_TRY(ty->launch_col_stream(dtype, &p, cur()));
-            else
-                HIP_TRY(ty->launch_col(dtype, &p, gx, gy, cur()));
+            HIP_TRY(ty->launch_col(dtype, &p, gx, gy, cur()));
         }
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(cur());
@@ -441,6 +392,7 @@ struct rl_deconv {
               const void* scale, int views, int in_mod = 0) {
         RowParams<T> p;
         p.in_mod = in_mod;
+        p.sub_one = sub_one ? 1 : 0;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -455,10 +407,7 @@ struct rl_deconv {
         p.frames = (int)gy;
         {
             TimedScope t(this, mode == ROW_RATIO ? TK_RATIO : mode == ROW_UPDATE ? TK_UPDATE : mode == ROW_FWD ? TK_FWD : TK_INV);
-            if (tx->launch_row_stream && (((streaming & 2) && mode == ROW_RATIO) || ((streaming & 4) && mode == ROW_UPDATE && views == 1)))
-                HIP_TRY(tx->launch_row_stream(dtype, mode, &p, cur()));
-            else
-                HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, cur()));
+            HIP_TRY(tx->launch_row(dtype, mode, &p, (pairs + Q - 1) / Q, gy, cur()));
         }
         if (rl::debug_sync()) {
             hipError_t e = hipStreamSynchronize(cur());
@@ -495,26 +444,31 @@ struct rl_deconv {
     // doubles, through a device staging buffer.
     static constexpr size_t kStageElems = (size_t)16 << 20;   // 128 MiB of float64
     double* stage_dev = nullptr;   // [kStageElems] + per-frame sums / targets
-    double* stage_aux = nullptr;   // [2 * B]
+    double* stage_aux = nullptr;   // [B] per-frame targets
+    double* stage_sums = nullptr;  // [B * V] per-image sums
     int ensure_stage() {
         if (stage_dev) return RL_OK;
         HIP_TRY(hipMalloc((void**)&stage_dev, kStageElems * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&stage_aux, 2 * (size_t)B * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&stage_aux, (size_t)B * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&stage_sums, (size_t)B * V * sizeof(double)));
         bytes += kStageElems * sizeof(double);
         return RL_OK;
     }
     // images: `count` images of n_img() pixels; target (host, per image) may be nullptr
-    int upload_images(const double* src, void* dst, size_t count, const double* target) {
+    // sums_out (host, optional): the images' sums as uploaded (before any scaling)
+    int upload_images(const double* src, void* dst, size_t count, const double* target, std::vector<double>* sums_out = nullptr) {
         RL_TRY(ensure_stage());
         const size_t n = n_img();
         if (n > kStageElems) return fail(RL_ERR_UNSUPPORTED, "image larger than the staging buffer");
         const size_t per = kStageElems / n;
+        if (sums_out) sums_out->assign(count, 0.0);
         if (target) HIP_TRY(hipMemcpyAsync(stage_aux, target, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         for (size_t f0 = 0; f0 < count; f0 += per) {
             const size_t nf = f0 + per <= count ? per : count - f0;
             HIP_TRY(hipMemcpyAsync(stage_dev, src + f0 * n, nf * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(aux_scale_convert(dtype, stage_dev, (char*)dst + f0 * n * esize(dtype), n, nf,
-                                      target ? stage_aux + f0 : nullptr, stage_aux + B + f0, ctx->stream));
+                                      target ? stage_aux + f0 : nullptr, stage_sums + f0, ctx->stream, target != nullptr || sums_out != nullptr));
+            if (sums_out) HIP_TRY(hipMemcpyAsync(sums_out->data() + f0, stage_sums + f0, nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next slice
         }
         return RL_OK;
@@ -566,9 +520,13 @@ struct rl_deconv {
         if (c < 1) c = 1;
         if (c >= B) return B;
         // equal slices (a short last slice would run its 4 launches per iteration nearly empty)
+        const int fit = c;                       // frames the budget holds
         const int slices = (B + c - 1) / c;
         c = (B + slices - 1) / slices;
-        if (c > 8) c = (c + 7) / 8 * 8;
+        if (c > 8) {                               // whole groups of 8 frames: up if that still fits the budget, down otherwise
+            const int up = (c + 7) / 8 * 8;
+            c = up <= fit ? up : std::max(8, fit / 8 * 8);
+        }
         if (pair && (c & 1)) ++c;   // slices of whole frame pairs
         return c >= B ? B : c;
     }
@@ -603,21 +561,6 @@ struct rl_deconv {
         } scale_guard{q_ratio, q_ratio};
         if (from_ones) q_ratio = q_est;
         if (sep) return sep_iterate(f0, nf);
-        if (pair && V > 1) {   // est pair spectra in spec_a, the V view images of every pair in spec_b, views summed in the column pass
-            void* sa = pair_spec(f0);
-            void* sb = (char*)spec_b + (size_t)(f0 / 2) * V * n_spec_pair() * 2 * esize(dtype);
-            const int np = (nf + 1) / 2;
-            const void* m = off(meas, (size_t)f0 * V * n_img());
-            if (first) {
-                RL_TRY(row_pair(ROW_RATIO, nf, spec_ones_pair, sb, m, nullptr, nullptr, V, V));
-            } else {
-                RL_TRY(col_pair(sa, sb, np, COL_H));
-                RL_TRY(row_pair(ROW_RATIO, nf, sb, sb, m, nullptr, nullptr, 0, V));
-            }
-            RL_TRY(col_pair(sb, sa, np, COL_HT_FUSED));
-            RL_TRY(row_pair(ROW_UPDATE, nf, sa, drop_last_spectrum ? nullptr : sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
-            return RL_OK;
-        }
         if (pair) {   // the whole iteration in the pair spectra, in place
             void* sp = pair_spec(f0);
             const int np = (nf + 1) / 2;
@@ -688,8 +631,7 @@ struct rl_deconv {
         void* sb = off(spec_b, (size_t)f0 * V * n_spec() * 2);
         // (frame pairs: the other lane's slice iterates in spec_a in the pair layout, whose slice boundaries are not
         // this layout's -- the simulation then stays in spec_b, in place)
-        // (V > 1: the frame spectra go through scratch, which is idle during run_slices and large enough -- deconv_build checks)
-        void* sa = !pair ? off(spec_a, (size_t)f0 * n_spec() * 2) : V == 1 ? sb : off(scratch, (size_t)f0 * V * n_img());
+        void* sa = !pair ? off(spec_a, (size_t)f0 * n_spec() * 2) : sb;
         RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, sa, off(obj, (size_t)f0 * n_img()), nullptr, nullptr));
         RL_TRY(col(sa, sb, nf, true));
         RL_TRY(row(ROW_INV, (unsigned)(nf * V), sb, nullptr, nullptr, off(noiseless, (size_t)f0 * V * n_img()), nullptr));
@@ -710,18 +652,12 @@ struct rl_deconv {
     // (optionally restart from est = 1 and) run k iterations, slice by slice
     int run_iterations(int k, bool restart) { return run_slices(k, restart, false, 0, 0); }
     int run_slices(int k, bool restart, bool simulate, int rng_kind, uint64_t seed) {
-        const bool use_fused = fused_available() && k > 0 && !sep && !pair;
         const int cf = chunk_frames();
         const int slices = (B + cf - 1) / cf;
         const int nl = slices < lanes ? slices : lanes;
-        if (use_fused && !restart && !simulate) {   // nothing to do per slice: straight to the fused launch
-            RL_TRY(fused_launch(0, B, k));
-            iterations += k;
-            return RL_OK;
-        }
         // Lanes stay open between the back-to-back cycles of rl_deconv_bench_cycles (defer_join): slice s of every cycle
         // goes to the same lane, so stream order alone keeps each slice's buffers consistent and the lanes need not meet.
-        const bool keep_open = defer_join && nl > 1 && !use_fused && !sim_ahead;
+        const bool keep_open = defer_join && nl > 1;
         if (nl > 1 && !lanes_open) {
             RL_TRY(ensure_lanes());
             HIP_TRY(hipEventRecord(fork, ctx->stream));
@@ -753,51 +689,25 @@ struct rl_deconv {
             if (e != hipSuccess) return fail(RL_ERR_HIP, std::string("Poisson kernels: ") + hipGetErrorString(e));
             return RL_OK;
         };
-        // Simulation ahead of the RL lanes (RLSTED_SIM_AHEAD=1, off by default): the forward model and the
-        // Poisson draws of every slice go to a stream of their own, each slice's RL lane waits for its
-        // event.  The idea: Poisson is float64 / integer ALU work, the RL kernels memory and LDS work.
-        // Measured 16.5 k against 17.2 k frames/s: the simulations of all slices then stream 2.3 GB through
-        // the memory system while the first slices iterate, and push their working sets out of the
-        // Infinity Cache.  Slice by slice on the RL lanes (below) the same overlap happens between lanes.
-        const bool ahead = simulate && nl > 1 && sim_ahead;
-        if (ahead) {
-            if (!sim_stream) HIP_TRY(hipStreamCreateWithFlags(&sim_stream, hipStreamNonBlocking));
-            while ((int)sim_done.size() < slices) {
-                hipEvent_t ev;
-                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                sim_done.push_back(ev);
-            }
-            HIP_TRY(hipStreamWaitEvent(sim_stream, fork, 0));
-            active = sim_stream;
-            for (int sl = 0, f0 = 0; f0 < B && rc == RL_OK; f0 += cf, ++sl) {
-                rc = simulate_slice(sl, f0, f0 + cf <= B ? cf : B - f0);
-                if (rc == RL_OK && hipEventRecord(sim_done[sl], sim_stream) != hipSuccess) rc = fail(RL_ERR_HIP, "hipEventRecord");
-            }
-        }
+        // (Round 1 also tried the simulation of all slices ahead of the RL lanes on a stream of its own: 16.5 k against 17.2 k
+        // frames/s -- 2.3 GB streamed through the memory system while the first slices iterate push their working sets out of the
+        // Infinity Cache.  Slice by slice on the RL lanes the same overlap happens between lanes.)
         for (int sl = 0, f0 = 0; f0 < B && rc == RL_OK; f0 += cf, ++sl) {
             const int nf = f0 + cf <= B ? cf : B - f0;
             active = nl > 1 ? lane_stream[sl % nl] : nullptr;
-            if (ahead) {
-                if (hipStreamWaitEvent(lane_stream[sl % nl], sim_done[sl], 0) != hipSuccess) rc = fail(RL_ERR_HIP, "hipStreamWaitEvent");
-            } else if (simulate) {
-                rc = simulate_slice(sl, f0, nf);
-            }
-            const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !use_fused && !sep;
+            if (simulate) rc = simulate_slice(sl, f0, nf);
+            const bool shortcut = restart && ones_shortcut && spec_ones && k > 0 && !sep;
             if (restart && rc == RL_OK) rc = start_estimate_chunk(f0, nf, !shortcut);
             // Frame pairs: the last iteration of a run of >= 4 does not transform its estimate forward again (1 of 2 row
             // transforms of that launch, the spectrum store); an rl_deconv_iterate that continues rebuilds it with one ROW_FWD.
             const bool drop = pair && k >= 4 && !keep_last_spectrum;
-            for (int i = 0; i < k && rc == RL_OK && !use_fused; ++i) {
+            for (int i = 0; i < k && rc == RL_OK; ++i) {
                 drop_last_spectrum = drop && i == k - 1;
                 rc = iterate_chunk(f0, nf, shortcut && i == 0, restart && i == 0);
             }
             drop_last_spectrum = false;
         }
         active = nullptr;
-        if (ahead) {   // on errors a lane may not have waited for every slice: join the simulation stream too
-            HIP_TRY(hipEventRecord(fork, sim_stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, fork, 0));
-        }
         if (nl > 1 && (!keep_open || rc != RL_OK)) {   // join, also on errors: the context's stream continues after every lane
             for (int l = 0; l < nl; ++l) {
                 HIP_TRY(hipEventRecord(lane_done[l], lane_stream[l]));
@@ -808,13 +718,12 @@ struct rl_deconv {
             lanes_open = true;
         }
         RL_TRY(rc);
-        if (use_fused) RL_TRY(fused_launch(0, B, k));   // all iterations of all frames, after the lanes have joined
         if (restart) {
             est_ready = true;
             spec_valid = true;
             iterations = 0;
         }
-        if (pair && k >= 4 && !use_fused && !keep_last_spectrum) spec_valid = false;   // the last iteration left no spectrum behind
+        if (pair && k >= 4 && !keep_last_spectrum) spec_valid = false;   // the last iteration left no spectrum behind
         iterations += k;
         return RL_OK;
     }
@@ -897,18 +806,11 @@ int rl_deconv_destroy(rl_deconv* h) {
     hipStreamSynchronize(h->ctx->stream);
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
         if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
-    if (h->sim_stream) {
-        hipStreamSynchronize(h->sim_stream);
-        hipStreamDestroy(h->sim_stream);
-    }
-    for (hipEvent_t ev : h->sim_done) hipEventDestroy(ev);
     void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
-                    h->stage_dev, h->stage_aux, h->slice_ws, h->key_seeds, h->key_ids};
+                    h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
-    if (h->fused_ctrl) hipFree(h->fused_ctrl);
-    if (h->fused_status) hipHostFree(h->fused_status);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->fork) hipEventDestroy(h->fork);
@@ -938,9 +840,12 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     RL_TRY(ctx->twiddles(h->ty, h->dtype, &h->twy, true));
     RL_TRY(ctx->twiddles(h->tx, h->dtype, &h->twx));
     const size_t es = esize(h->dtype), B = (size_t)h->B, V = (size_t)h->V;
+    // (measured, pitch lx against lx + 32: 512^2 18.7 k against 18.1 k frames/s, 2048^2 690 against 716, 4096^2 K = 100 28.0 against 28.6)
+    h->pair_pitch = h->lx + (getenv("RLSTED_PAIR_PAD") ? std::max(0, atoi(getenv("RLSTED_PAIR_PAD"))) / 8 * 8 : (h->lx >= 1152 ? 32 : 0));
     struct Req { void** p; size_t n; };
     const Req reqs[] = {
-        {&h->psf_hat, V * h->ly * h->pitch * 2 * es}, {&h->spec_a, B * h->n_spec() * 2 * es},
+        {&h->psf_hat, V * h->ly * h->pitch * 2 * es},   // (spec_a: the frames' half spectra or the pairs' full ones)
+        {&h->spec_a, std::max(B * h->n_spec(), (B + 1) / 2 * h->n_spec_pair()) * 2 * es},
         {&h->spec_b, B * V * h->n_spec() * 2 * es},   {&h->obj, B * h->n_img() * es},
         {&h->noiseless, B * V * h->n_img() * es},     {&h->meas, B * V * h->n_img() * es},
         {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
@@ -1027,6 +932,27 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         h->bytes += ones_bytes + RL_STREAM_SLACK;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // ---- f32 plans: the normaliser to float64 rounding from the PSFs' integral images (aux_box_norm) ----
+    if (h->exact_norm) {
+        const size_t py = h->py, px = h->px, stride = (py + 1) * (px + 1);
+        std::vector<double> integ(V * stride, 0.0);
+        for (size_t v = 0; v < V; ++v)
+            for (size_t a = 0; a < py; ++a) {
+                double row = 0.0;   // running sum of PSF row a
+                for (size_t b = 0; b < px; ++b) {
+                    row += psfs[(v * py + a) * px + b];
+                    integ[v * stride + (a + 1) * (px + 1) + (b + 1)] = integ[v * stride + a * (px + 1) + (b + 1)] + row;
+                }
+            }
+        double* integ_dev = nullptr;
+        HIP_TRY(hipMalloc((void**)&integ_dev, integ.size() * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(integ_dev, integ.data(), integ.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = aux_box_norm(h->dtype, integ_dev, h->norm, h->V, h->py, h->px, h->ny, h->nx, ctx->stream);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(integ_dev);
+        HIP_TRY(e);
+        HIP_TRY(e2);
+    }
     // ---- strategy selection: direct separable stencils when every view is rank 1 and small ----
     const int sep_mode = getenv("RLSTED_SEP") ? atoi(getenv("RLSTED_SEP")) : 1;
     const int max_taps = getenv("RLSTED_SEP_MAX_TAPS") ? atoi(getenv("RLSTED_SEP_MAX_TAPS")) : 16;
@@ -1104,14 +1030,10 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     // 4096^2 -12 % time per iteration -- but the per-frame loop's Hermitian split averages the two mirrored halves of every
     // row spectrum, the pair loop does not, and where f32 has no margin left that shows: white noise at 2048^2, K = 20,
     // 8.8e-6 -> 1.05e-5 against the f64 plan.  Default there: per frame (RLSTED_PAIR=1 pairs them).
-    const bool short_rows = h->tx->T == 64;
-    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32 && V == 1 && short_rows);
-    const bool pair_views_ok = V == 1 ? h->inplace
-                                      : (h->fuse_views && h->wave_private_y() && h->n_spec() * 2 <= V * h->n_img());   // (frame spectra fit scratch)
-    // (an explicitly requested fused kernel or streaming flavour keeps the per-frame layout they are written for)
+    const bool want_pair = getenv("RLSTED_PAIR") ? atoi(getenv("RLSTED_PAIR")) != 0 : (h->dtype == RL_F32 && V == 1);
+    const bool pair_views_ok = V == 1 && h->inplace && h->B >= 2;   // (a single frame has no partner -- and the set-up below fills two frames of ones)
     // an odd batch leaves its last pair half empty: allowed where the pair spectra still fit the per-frame buffers
-    const bool pair_fits = ((size_t)(h->B + 1) / 2) * h->n_spec_pair() <= (size_t)h->B * h->n_spec();
-    if (want_pair && !h->sep && !h->fused && h->streaming == 0 && pair_views_ok && pair_fits && h->tx->launch_row_pair && h->psf_transposed()) {
+    if (want_pair && !h->sep && pair_views_ok && h->tx->launch_row_pair && h->psf_transposed()) {
         const size_t nz = V * (size_t)h->lx * h->ly;
         void *wy = nullptr, *wx = nullptr, *psf_dev = nullptr, *s1 = nullptr;
         RL_TRY(ctx->plain_twiddles(h->ly, &wy));
@@ -1139,7 +1061,8 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
             HIP_TRY(e2);
             h->bytes += nz * es + RL_STREAM_SLACK;
         }
-        h->pair = true;
+        h->pair = h->pair_layout = true;
+        if (getenv("RLSTED_PAIR_MAX_RATIO")) h->pair_max_ratio = atof(getenv("RLSTED_PAIR_MAX_RATIO"));
         // H(1 + i) of a pair of ones frames, column part (one spectrum per view): what every pair's first iteration reads
         const size_t ones_bytes = V * h->n_spec_pair() * 2 * es;
         HIP_TRY(hipMalloc(&h->spec_ones_pair, ones_bytes + RL_STREAM_SLACK));
@@ -1165,25 +1088,25 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
     rl_deconv* h = new rl_deconv;
     h->ctx = ctx;
     h->V = n_psf; h->py = py; h->px = px; h->B = batch; h->ny = ny; h->nx = nx; h->dtype = dtype;
-    if (getenv("RLSTED_STREAM")) h->streaming = atoi(getenv("RLSTED_STREAM"));
     if (getenv("RLSTED_INPLACE")) h->inplace = atoi(getenv("RLSTED_INPLACE")) != 0;
-    if (getenv("RLSTED_SIM_AHEAD")) h->sim_ahead = atoi(getenv("RLSTED_SIM_AHEAD")) != 0;
     if (getenv("RLSTED_COL_ORDER")) h->col_order = atoi(getenv("RLSTED_COL_ORDER")) < 1 ? 1 : atoi(getenv("RLSTED_COL_ORDER"));
     if (getenv("RLSTED_Q_EXP_EST")) h->q_est = std::ldexp(1.0f, 14 - atoi(getenv("RLSTED_Q_EXP_EST")));
     if (getenv("RLSTED_Q_EXP_RATIO")) h->q_ratio = std::ldexp(1.0f, 14 - atoi(getenv("RLSTED_Q_EXP_RATIO")));
     if (getenv("RLSTED_ONES_SHORTCUT")) h->ones_shortcut = atoi(getenv("RLSTED_ONES_SHORTCUT")) != 0;
-    if (getenv("RLSTED_FUSED")) h->fused = atoi(getenv("RLSTED_FUSED"));
     if (getenv("RLSTED_KEEP_LAST_SPECTRUM")) h->keep_last_spectrum = atoi(getenv("RLSTED_KEEP_LAST_SPECTRUM")) != 0;
-    if (getenv("RLSTED_FUSED_W")) h->fused_team = std::max(1, atoi(getenv("RLSTED_FUSED_W")));
-    if (getenv("RLSTED_FUSED_WGS")) h->fused_wgs = std::max(1, atoi(getenv("RLSTED_FUSED_WGS")));
-    if (getenv("RLSTED_FUSED_ACQ")) h->fused_acq = atoi(getenv("RLSTED_FUSED_ACQ")) != 0;
-    if (getenv("RLSTED_FUSED_S")) h->fused_streams = std::min(std::max(1, atoi(getenv("RLSTED_FUSED_S"))), kFusedMaxStreams);
     if (getenv("RLSTED_LANES")) {
         h->lanes = atoi(getenv("RLSTED_LANES"));
         if (h->lanes < 1) h->lanes = 1;
         if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
     }
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
+    h->exact_norm = getenv("RLSTED_EXACT_NORM") ? atoi(getenv("RLSTED_EXACT_NORM")) != 0 : (dtype == RL_F32);
+    {   // ratio - 1 needs H_t(ones) == the normaliser: every PSF value >= 0 (and not the 16-bit storage study, whose scales assume ratio spectra)
+        bool nonneg = true;
+        for (size_t i = 0; i < (size_t)n_psf * py * px && nonneg; ++i) nonneg = psfs[i] >= 0.0;
+        const bool want = getenv("RLSTED_SUB_ONE") ? atoi(getenv("RLSTED_SUB_ONE")) != 0 : (dtype == RL_F32 && RL_SPEC_QUANT == 0);
+        h->sub_one = want && nonneg;
+    }
     int r = deconv_build(h, psfs);
     if (r != RL_OK) {
         std::string keep = rl::last_error();
@@ -1208,7 +1131,8 @@ int rl_deconv_set_object(rl_deconv* h, const double* obj, const double* total_br
     if (!h || !obj) return fail(RL_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(h->ctx->device));
     // :505-506  obj *= total_brightness / obj.sum(), per frame, on the device
-    RL_TRY(h->upload_images(obj, h->obj, (size_t)h->B, total_brightness));
+    RL_TRY(h->upload_images(obj, h->obj, (size_t)h->B, total_brightness, &h->obj_level));
+    if (total_brightness) h->obj_level.assign(total_brightness, total_brightness + h->B);   // the frames' sums after scaling
     HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
     RL_TRY(h->forward_object());
     HIP_TRY(hipEventRecord(h->ev1, h->ctx->stream));
@@ -1229,6 +1153,8 @@ int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed) {
     HIP_TRY(aux_poisson(h->dtype, h->noiseless, h->meas, (unsigned)h->n_img(), (unsigned)(h->B * h->V), 0, seed, rng_kind,
                         h->scratch, h->ctx->stream));
     HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    h->meas_level = h->obj_level;   // the measurement's level follows the object's
+    h->choose_loop(h->meas_level);
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;
@@ -1251,6 +1177,8 @@ int rl_deconv_simulate_keyed(rl_deconv* h, int rng_kind, const uint64_t* seeds, 
                         h->scratch, h->ctx->stream, (const unsigned long long*)h->key_seeds, (const unsigned*)h->key_ids,
                         (unsigned)h->V));
     HIP_TRY(hipStreamSynchronize(h->ctx->stream));   // the host arrays may go away
+    h->meas_level = h->obj_level;
+    h->choose_loop(h->meas_level);
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;
@@ -1259,7 +1187,13 @@ int rl_deconv_simulate_keyed(rl_deconv* h, int rng_kind, const uint64_t* seeds, 
 int rl_deconv_set_measurement(rl_deconv* h, const double* noisy) {
     if (!h || !noisy) return fail(RL_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(h->ctx->device));
-    RL_TRY(h->upload(noisy, h->meas, (size_t)h->B * h->V * h->n_img()));
+    {
+        std::vector<double> sums;
+        RL_TRY(h->upload_images(noisy, h->meas, (size_t)h->B * h->V, nullptr, &sums));
+        h->meas_level.assign((size_t)h->B, 0.0);
+        for (size_t i = 0; i < sums.size(); ++i) h->meas_level[i / h->V] += sums[i];
+        h->choose_loop(h->meas_level);
+    }
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;
@@ -1301,7 +1235,6 @@ int rl_deconv_iterate(rl_deconv* h, int k) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_iter_ms = ms;
-    RL_TRY(h->fused_check());
     return RL_OK;
 }
 
@@ -1372,6 +1305,8 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     if (k < 0 || reps < 1) return fail(RL_ERR_INVALID, "bad k / reps");
     HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
+    h->meas_level = h->obj_level;   // every cycle draws its measurement from the object
+    h->choose_loop(h->meas_level);
     const auto t_start = std::chrono::steady_clock::now();
     HIP_TRY(hipEventRecord(h->ev0, s));
     for (int r = 0; r < reps; ++r) {
@@ -1397,7 +1332,6 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
     if (getenv("RLSTED_DEBUG_ENQUEUE"))   // how far the host runs ahead of the device: enqueue time against device time
         fprintf(stderr, "rl_deconv_bench_cycles: host enqueue %.3f ms, device %.3f ms\n",
                 std::chrono::duration<double, std::milli>(t_enq - t_start).count(), (double)ms);
-    RL_TRY(h->fused_check());
     return RL_OK;
 }
 
@@ -1407,7 +1341,7 @@ int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectru
     if (frame_pairs) *frame_pairs = h->pair ? 1 : 0;
     if (separable) *separable = h->sep ? 1 : 0;
     if (real_psf_spectrum) *real_psf_spectrum = h->psf_hat_re ? 1 : 0;
-    if (fused_rl) *fused_rl = h->fused_available() ? 1 : 0;
+    if (fused_rl) *fused_rl = 0;   // (the persistent XCD-resident loop of round 2 lost to the four-launch iteration and was removed)
     return RL_OK;
 }
 
@@ -1477,6 +1411,8 @@ int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, doubl
     if (h->sep) return fail(RL_ERR_UNSUPPORTED, "per-kernel timing covers the FFT strategy; this plan runs the separable stencils");
     HIP_TRY(hipSetDevice(h->ctx->device));
     HIP_TRY(hipDeviceSynchronize());
+    h->meas_level = h->obj_level;
+    h->choose_loop(h->meas_level);
     h->timed.clear();
     h->events_used = 0;
     h->timing = true;
@@ -1486,7 +1422,6 @@ int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, doubl
     RL_TRY(rc);
     HIP_TRY(e);
     h->have_meas = true;
-    RL_TRY(h->fused_check());
     double sum[rl_deconv::TK_COUNT] = {0}, cnt[rl_deconv::TK_COUNT] = {0};
     for (const auto& t : h->timed) {
         float ms = 0;
@@ -1498,7 +1433,9 @@ int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, doubl
         avg_ms[i] = cnt[i] > 0 ? sum[i] / cnt[i] : 0.0;
         if (launches) launches[i] = cnt[i];
     }
-    if (frames_per_launch) *frames_per_launch = (double)((h->fused_available() && k > 0) ? h->B : h->chunk_frames());
+    avg_ms[7] = 0.0;   // (was the fused loop's slot; the arrays keep their 8 entries)
+    if (launches) launches[7] = 0.0;
+    if (frames_per_launch) *frames_per_launch = (double)h->chunk_frames();
     return RL_OK;
 }
 

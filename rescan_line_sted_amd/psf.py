@@ -81,14 +81,22 @@ def generate_psfs(shape, excitation_brightness, depletion_brightness, blur_sigma
         print(" ...done.")
     psfs = _as_dict(psf_type, arrays, ny, nx)
     if output_dir is not None:
-        _dump_psfs(psfs, psf_type, output_dir)
+        extras = _line_extras(ny, nx, excitation_brightness, depletion_brightness, blur_sigma, int(scalars[0])) if psf_type == 'line' else None
+        _dump_psfs(psfs, psf_type, output_dir, extras)
     return psfs
 
 
-def _dump_psfs(psfs, psf_type, output_dir):
-    """Optional TIFF dump, ref:311-346 (file names as in the reference; the
-    unscaled rescan ring buffer is an internal of the device kernel and is not
-    written)."""
+def _line_extras(ny, nx, excitation_brightness, depletion_brightness, blur_sigma, ratio):
+    """The two intermediates of the 'line' branch that the reference also writes (ref:339-341): the emission PSF and
+    the unscaled rescan ring (1, ny, ratio * nx)."""
+    emission, unscaled = np.empty((1, ny, nx)), np.empty((1, ny, ratio * nx))
+    check(lib.rl_psf_generate_line_extras(_ctx().handle, ny, nx, float(excitation_brightness), float(depletion_brightness),
+                                          float(blur_sigma), int(ratio), ptr(emission), ptr(unscaled)))
+    return {'emission_psf.tif': emission, 'sted_psf_line_rescan_unscaled.tif': unscaled}
+
+
+def _dump_psfs(psfs, psf_type, output_dir, extras=None):
+    """Optional TIFF dump, ref:311-346: the reference's nine (line) / five (point) files under its file names."""
     from . import np_tif
     if not os.path.exists(output_dir):
         os.mkdir(output_dir)
@@ -96,6 +104,8 @@ def _dump_psfs(psfs, psf_type, output_dir):
     for key in _POINT_KEYS:
         np_tif.array_to_tif(psfs[key], os.path.join(output_dir, key + sfx))
     if psf_type == 'line':
+        for name in ('emission_psf.tif', 'sted_psf_line_rescan_unscaled.tif'):
+            np_tif.array_to_tif((extras or {})[name], os.path.join(output_dir, name))
         np_tif.array_to_tif(psfs['rescan_sted'], os.path.join(output_dir, 'sted_psf_line_rescan.tif'))
         np_tif.array_to_tif(psfs['descan_sted'], os.path.join(output_dir, 'sted_psf_line_descan.tif'))
 
@@ -126,7 +136,9 @@ def psf_report(psf_type, excitation_brightness, depletion_brightness,
                                          steps_per_excitation_psf_width, pulses_per_position, True)
     psfs = _as_dict(psf_type, arrays, n, n)
     if output_dir is not None:
-        _dump_psfs(psfs, psf_type, output_dir)
+        extras = (_line_extras(n, n, excitation_brightness, depletion_brightness, blur_sigma, int(rep[6]))
+                  if psf_type == 'line' else None)
+        _dump_psfs(psfs, psf_type, output_dir, extras)
     if verbose:
         if psf_type == 'line':
             print(" Neareset integer:", int(rep[6]))

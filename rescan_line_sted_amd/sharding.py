@@ -48,20 +48,56 @@ class DeviceArray:
                                          'version': 2, 'strides': None}
 
 
-def rendezvous_path():
-    """Where rank 0 leaves the RCCL unique id for the other ranks of this launch: all ranks of one
-    launcher share a parent process and a MASTER_PORT."""
-    tag = '%d_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
-    return os.path.join(tempfile.gettempdir(), 'rlsted_rccl_%s.id' % tag)
+def _launcher_nonce():
+    """Identifies THIS launch: the launcher's pid together with its start time (clock ticks since boot, field 22 of
+    /proc/<pid>/stat -- a recycled pid gets another value), the rendezvous port, the launcher's run id and restart count.
+    Every rank of one launch computes the same string; a crashed earlier launch, even with the same pid and port, another."""
+    ppid = os.getppid()
+    start = '0'
+    try:
+        with open('/proc/%d/stat' % ppid) as f:
+            start = f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
+    return '%d_%s_%s_%s_%s' % (ppid, start, os.environ.get('MASTER_PORT', '0'),
+                               ''.join(c for c in os.environ.get('TORCHELASTIC_RUN_ID', 'none') if c.isalnum() or c in '-_')[:40],
+                               os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
+
+
+def rendezvous_dir():
+    """A directory only this user can enter (0700): the id file cannot be pre-created or replaced by someone else."""
+    base = os.environ.get('XDG_RUNTIME_DIR', '')
+    if not (base and os.path.isdir(base) and os.access(base, os.W_OK | os.X_OK)):
+        base = tempfile.gettempdir()
+    d = os.path.join(base, 'rlsted-%d' % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError('%s is not a private directory of this user' % d)
+    return d
+
+
+_comm_seq = [0]     # communicators created by this process so far: every rank creates them in the same order
+
+
+def rendezvous_path(seq=None):
+    """Where rank 0 leaves the RCCL unique id for the other ranks of this launch."""
+    return os.path.join(rendezvous_dir(), 'rccl_%s_%d.id' % (_launcher_nonce(), _comm_seq[0] if seq is None else seq))
 
 
 def exchange_unique_id(rank, make_id, path=None, timeout=300.0, nbytes=128):
-    """Rank 0 creates the id and publishes it atomically in a file; the others wait for the file."""
+    """Rank 0 removes whatever is at `path`, creates the id and publishes it atomically (exclusive create, mode 0600,
+    then rename); the others wait for a file of the right size."""
     path = path or rendezvous_path()
     if rank == 0:
+        try:
+            os.remove(path)            # never hand out a file this call did not write
+        except OSError:
+            pass
         blob = make_id()
         tmp = '%s.%d.tmp' % (path, os.getpid())
-        with open(tmp, 'wb') as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, 'wb') as f:
             f.write(blob)
         os.replace(tmp, path)
         return blob
@@ -93,6 +129,7 @@ class RcclComm:
             _lib.check(_lib.lib.rl_comm_unique_id(buf))
             return buf.raw
         self._path = path or rendezvous_path()
+        _comm_seq[0] += 1
         blob = exchange_unique_id(self.rank, make_id, self._path)
         self.handle = ctypes.c_void_p()
         _lib.check(_lib.lib.rl_comm_create(self.ctx.handle, self.rank, self.world, ctypes.c_char_p(blob),

@@ -66,9 +66,6 @@ static void run_grid(int gx, int gy, int nthreads, size_t lds_bytes, Body body) 
     for (auto& b : wbar) pthread_barrier_destroy(&b);
 }
 
-// > 0: run the streaming (persistent) bodies with that many workgroups where they apply
-static int g_stream_nwg = 0;
-
 template <class Cfg, typename T>
 static std::vector<cx<T>> twiddles_of() {   // the per-pass table the device plan uploads for one geometry
     constexpr int n = PassTw<Cfg, false, 0>::TOTAL;
@@ -101,16 +98,6 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     const int gy = (mode == COL_PER_IMAGE) ? frames * V : frames;   // as rlsted.cpp col_t()
     if (mode != COL_PER_IMAGE && !WavePrivate<Cfg>::value) return -3;
     p.images = gy; p.order = 1;
-    if constexpr (WavePrivate<Cfg>::value) {
-        if (g_stream_nwg > 0 && mode == COL_PER_IMAGE) {
-            const int nwg = g_stream_nwg;
-            run_grid(nwg, 1, 64 * C, ((size_t)C * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
-                     [&](int tid, int bx, int, unsigned char* lds, EmuSync& s) {
-                         colstream_body<Cfg, C, T>(p, tid, bx, nwg, reinterpret_cast<cx<T>*>(lds), s);
-                     });
-            return 0;
-        }
-    }
     run_grid((kx + C - 1) / C, gy, Cfg::T * C, (size_t)C * LdsSlots<Cfg>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  if constexpr (WavePrivate<Cfg>::value)
@@ -131,19 +118,6 @@ static int row_m(const RowParams<T>& p, int gy) {
     using Cfg = typename CF::Cfg;
     constexpr int Q = sizeof(T) == 4 ? CF::Q32 : CF::Q64;
     const int pairs = (p.ny + 1) / 2;
-    if constexpr (WavePrivate<Cfg>::value && (MODE == ROW_RATIO || MODE == ROW_UPDATE)) {
-        if (g_stream_nwg > 0 && (MODE == ROW_RATIO || p.V == 1)) {
-            constexpr int QS = 2;   // two waves per workgroup: several items per wave at test sizes
-            const int nwg = g_stream_nwg;
-            RowParams<T> ps = p;
-            ps.frames = gy;
-            run_grid(nwg, 1, 64 * QS, ((size_t)QS * LdsSlots<Cfg>::value + StreamTw<Cfg>::COUNT) * sizeof(cx<T>),
-                     [&](int tid, int bx, int, unsigned char* lds, EmuSync& s) {
-                         rowstream_body<Cfg, QS, MODE, T>(ps, tid, bx, nwg, reinterpret_cast<cx<T>*>(lds), s);
-                     });
-            return 0;
-        }
-    }
     run_grid((pairs + Q - 1) / Q, gy, Cfg::T * Q, (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
@@ -161,11 +135,16 @@ static int row_m(const RowParams<T>& p, int gy) {
     return 0;
 }
 
+// RowParams::sub_one of every row launch (conv_kernels.hpp rl_ratio: ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE
+// multiplies by max(1 + acc / norm, 0))
+static int g_sub_one = 0;
+
 template <int L, typename T>
 static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, const T* scale,
                  int ny, int nx, int pitch, int V, int gy) {
     auto tw = twiddles<L, T>();
     RowParams<T> p;
+    p.sub_one = g_sub_one;
     p.spec_in = reinterpret_cast<const cx<T>*>(spec_in);
     p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
     p.src = src; p.dst = dst; p.norm = norm; p.scale = scale; p.tw = tw.data();
@@ -191,12 +170,7 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
 
 extern "C" {
 
-// nwg > 0: the streaming bodies (colstream_body / rowstream_body) with nwg persistent workgroups
-// stand in for the tiled ones wherever rlsted.cpp would launch them; 0: tiled bodies
-void emu_set_stream(int nwg) { g_stream_nwg = nwg; }
-
-// 1: spectra are in the blocked layout of conv_kernels.hpp (RL_SPEC_BLOCKED), 0: row-major
-int emu_spec_blocked() { return RL_SPEC_BLOCKED; }
+void emu_set_sub_one(int on) { g_sub_one = on; }
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
@@ -282,6 +256,7 @@ static int row_pair_t(int mode, const T* spec_in, T* spec_out, const T* src, T* 
         p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
         p.src = src; p.dst = dst; p.norm = norm; p.scale = nullptr; p.tw = tw.data();
         p.ny = ny; p.nx = nx; p.pitch = L; p.V = 1; p.frames = frames; p.in_mod = in_mod;
+        p.sub_one = g_sub_one;
         auto run = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             run_grid((ny + Q - 1) / Q, (frames + 1) / 2, 64 * Q, (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>),

@@ -197,6 +197,35 @@ def g8_fig2_psfs():
     save('g8_fig2_psfs.npz', **out)
 
 
+def g1b_line_dumps():
+    """psf_report('line', ..., output_dir=...) (ref:311-346): the nine files the reference writes, and the two arrays
+    among them that are not in the returned dict -- emission_psf.tif and sted_psf_line_rescan_unscaled.tif -- as read
+    back with the reference's own np_tif (float32 on disk)."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='_golden_dump_')
+    args = ('line', 0.25, 9.0, 8, 1)
+    st.psf_report(*args, verbose=False, output_dir=tmp)
+    names = sorted(os.listdir(tmp))
+    out = {'args': np.array(args[1:], dtype=np.float64), 'files': np.array(names)}
+    for n in ('emission_psf.tif', 'sted_psf_line_rescan_unscaled.tif', 'sted_psf_line_rescan.tif'):
+        out[n] = np_tif.tif_to_array(os.path.join(tmp, n))
+    shutil.rmtree(tmp)
+    save('g1b_line_dumps.npz', **out)
+
+
+def g8b_fig2_psfs_more():
+    """The two remaining line-rescan doses of BASELINE config 2 (2.5x: 6 orientations, 3.0x: 8), same layout as G8."""
+    out = {}
+    for name in ('2p5x_lr', '3p0x_lr'):
+        c = _fig2_psfs(name)
+        out[name + '/point_sted_psf'] = np.array(c['point_sted_psf'])
+        out[name + '/line_sted_psfs'] = np.array(c['line_sted_psfs'])
+        out[name + '/point'] = _tune_vec(c['point'])
+        out[name + '/line'] = _tune_vec(c['line'])
+    save('g8b_fig2_psfs_more.npz', **out)
+
+
 def g5_rl():
     """simulate (+noise from numpy's legacy RNG, seed 0) and RL estimates."""
     objs = _objects()
@@ -279,5 +308,5 @@ if __name__ == '__main__':
     os.makedirs('/tmp/_golden_tmp', exist_ok=True)
     for t in todo:
         {'g1': g1_psf_report, 'g2': g2_get_width, 'g3': g3_tune_psf,
-         'g4': g4_conv, 'g5': g5_rl, 'g8': g8_fig2_psfs,
+         'g4': g4_conv, 'g5': g5_rl, 'g8': g8_fig2_psfs, 'g8b': g8b_fig2_psfs_more, 'g1b': g1b_line_dumps,
          'g9': g9_progress, 'g10': g10_quality}[t]()

@@ -42,6 +42,10 @@ def test_gpus_2_launches_two_ranks_by_itself():
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
     assert d['final_gather']['frames_on_root'] == 2 * 4
     assert d['value'] > 0 and 'roofline' in d
+    # N > 1: the line also carries BASELINE config 4 through the sharder (cost-weighted partition, one gather on rank 0)
+    sw = d['fig2_sweep']
+    assert sw['tasks'] == 1152 and sw['frames_on_root'] == 1152 and sum(sw['tasks_per_rank']) == 1152
+    assert max(sw['cost_per_rank_rel']) < 1.01 and sw['gather_ms'] >= 0
 
 
 def test_under_the_drivers_launcher_command():

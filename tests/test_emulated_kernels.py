@@ -33,7 +33,7 @@ def emu():
 
 
 def _slack(a):
-    """Copy of `a` that is followed in memory by 16 KiB of slack: the streaming row bodies load
+    """Copy of `a` that is followed in memory by 16 KiB of slack: the lean row bodies load
     whole 64-lane segments, so lanes past the end of the last row read (and discard) bytes
     behind the array -- the device plan allocates RL_STREAM_SLACK behind every buffer for this."""
     a = np.ascontiguousarray(a)
@@ -79,23 +79,12 @@ class EmuPlan:
         else:
             self.psf_hat = ph
 
-    # Spectra live in device memory in the layout of conv_kernels.hpp (spec_off): row-major, or --
-    # RL_SPEC_BLOCKED builds -- [row pair][8-column block][row parity][8 columns] with the rows
-    # padded to an even count.  The tests keep natural (n, ny, pitch) arrays; they are converted at
-    # the kernel boundary.
+    # Spectra live in device memory row-major (conv_kernels.hpp spec_off); the kernels' unclamped loads need slack behind them.
     def _to_blocked(self, nat):
-        if not self.lib.emu_spec_blocked():          # row-major build: only the slack is added
-            return _slack(nat)
-        n, nye = nat.shape[0], (self.ny + 1) // 2 * 2
-        full = np.full((n, nye, self.pitch), np.nan + 1j * np.nan, dtype=self.ct)
-        full[:, :self.ny] = nat
-        return _slack(full.reshape(n, nye // 2, 2, self.pitch // 8, 8).transpose(0, 1, 3, 2, 4))
+        return _slack(nat)
 
     def _to_natural(self, blk):
-        if not self.lib.emu_spec_blocked():
-            return blk
-        n, nye = blk.shape[0], (self.ny + 1) // 2 * 2
-        return blk.reshape(n, nye // 2, self.pitch // 8, 2, 8).transpose(0, 1, 3, 2, 4).reshape(n, nye, self.pitch)[:, :self.ny]
+        return blk
 
     def _spectra(self, spec_in, spec_out):
         bin_ = self._to_blocked(spec_in) if spec_in is not None else None
@@ -309,36 +298,37 @@ def test_golden_rl_through_emulated_kernels(emu, golden):
     assert (np.abs(est[0] - ref) / np.abs(ref)).max() < 1e-9
 
 
-@pytest.mark.parametrize('nwg', [2, 5])
-def test_streaming_bodies_match_tiled_bodies(emu, nwg):
-    """The persistent, prefetching RL kernels (colstream_body / rowstream_body; wave-private
-    lengths, one view) against the tiled ones and the oracle: several work items per
-    workgroup, odd ny (a row pair with one row), partial last column tile, in-place spectra."""
-    emu.emu_set_stream.argtypes = [ctypes.c_int]
-    rng = np.random.default_rng(11)
+@pytest.mark.parametrize('Ly,Lx,V,fuse', [(256, 256, 1, False), (64, 192, 2, False), (256, 256, 3, True), (64, 64, 2, False)])
+def test_ratio_minus_one_iteration(emu, Ly, Lx, V, fuse):
+    """RowParams::sub_one (the f32 plans' default, conv_kernels.hpp rl_ratio): ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE
+    multiplies by max(1 + sum_v conv(ratio_v - 1, p_v) / norm, 0).  In float64 that is the plain iteration to rounding,
+    through the lean single-view bodies (256), the generic multi-view body (192 / 64: views summed raw, the sum clamped)
+    and the Fourier-domain view sum."""
+    emu.emu_set_sub_one.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(11 + V)
     ny, nx = 21, 30
-    psfs = [rng.random((1, 9, 7))]
+    psfs = [rng.random((1, 9, 7)) + 0.01 for _ in range(V)]            # non-negative: H_t(ones) is the normaliser
     obj = rng.random((2, ny, nx)) * 40
     d = orc.Deconvolver(psfs)
     d.create_data_from_object(obj, random_seed=0)
-    for _ in range(2):
+    for _ in range(3):
         d.iterate()
-    meas = np.array(d.noisy_measurement)[0][:, None]                                    # (B=2, V=1, ny, nx)
-    pl = EmuPlan(emu, psfs, ny, nx, 256, 256)          # a wave-private length on both axes
+    meas = np.array(d.noisy_measurement).transpose(1, 0, 2, 3)                          # (B=2, V, ny, nx)
+    pl = EmuPlan(emu, psfs, ny, nx, Ly, Lx)
     try:
-        emu.emu_set_stream(0)
-        tiled, _ = pl.rl(meas, 2)
-        emu.emu_set_stream(nwg)
-        streamed, _ = pl.rl(meas, 2)
+        emu.emu_set_sub_one(0)
+        plain, _ = pl.rl(meas, 3, fuse=fuse)
+        emu.emu_set_sub_one(1)
+        sub, _ = pl.rl(meas, 3, fuse=fuse)
     finally:
-        emu.emu_set_stream(0)
-    assert np.array_equal(streamed, tiled)          # same arithmetic, only the schedule differs
-    assert max_rel(streamed, d.estimate) < 1e-11
+        emu.emu_set_sub_one(0)
+    assert max_rel(sub, plain) < 1e-12
+    assert max_rel(sub, d.estimate) < 1e-11
 
 
-def test_streaming_bodies_l576_f32(emu):
-    """The headline geometry (576 = 9*8*8 with cross-lane tails) through the streaming bodies, f32."""
-    emu.emu_set_stream.argtypes = [ctypes.c_int]
+def test_ratio_minus_one_l576_f32(emu):
+    """The headline geometry (576 = 9*8*8 with cross-lane tails), f32, lean bodies, with and without `ratio - 1`."""
+    emu.emu_set_sub_one.argtypes = [ctypes.c_int]
     rng = np.random.default_rng(12)
     ny, nx = 20, 530
     psfs = [rng.random((1, 5, 41))]
@@ -350,14 +340,13 @@ def test_streaming_bodies_l576_f32(emu):
     meas = np.array(d.noisy_measurement)[0][:, None]                                    # (B=2, V=1, ny, nx)
     pl = EmuPlan(emu, psfs, ny, nx, 64, 576, np.float32)
     try:
-        emu.emu_set_stream(0)
-        tiled, _ = pl.rl(meas, 2)
-        emu.emu_set_stream(3)
-        streamed, _ = pl.rl(meas, 2)
+        emu.emu_set_sub_one(0)
+        plain, _ = pl.rl(meas, 2)
+        emu.emu_set_sub_one(1)
+        sub, _ = pl.rl(meas, 2)
     finally:
-        emu.emu_set_stream(0)
-    assert np.array_equal(streamed, tiled)
-    assert max_rel(streamed, d.estimate) < 2e-5
+        emu.emu_set_sub_one(0)
+    assert max_rel(plain, d.estimate) < 2e-5 and max_rel(sub, d.estimate) < 2e-5
 
 
 # ------------------------------------------------- long column transforms on the wave-private core
@@ -366,8 +355,6 @@ def test_streaming_bodies_l576_f32(emu):
 def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
     """colconv_outer_body: L = M * Li as M core transforms plus one radix-M step in registers (the f32
     column kernel of L = 2304 = 4 x 576 and 4608 = 8 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat), rows < ny."""
-    if emu.emu_spec_blocked():
-        pytest.skip('row-major spectra only')
     L, V, frames = M * Li, 2, 1
     pitch = (kx + 7) // 8 * 8
     rng = np.random.default_rng(Li + M + ny)
@@ -391,8 +378,6 @@ def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
 def test_outer_decimation_multi_view_modes(emu, Li, mode, ny, kx, real_psf):
     """The multi-view modes of colconv_outer_body (M = 4): COL_H_MULTI -- one forward transform feeds the V products
     and inverse transforms -- and COL_HT_SUM -- the V products are summed before one inverse transform."""
-    if emu.emu_spec_blocked():
-        pytest.skip('row-major spectra only')
     M, V, frames = 4, 3, 2
     L = M * Li
     pitch = (kx + 7) // 8 * 8
@@ -463,5 +448,19 @@ def test_frame_pair_row_kernels(emu, L, ny, nx, frames, sfx):
     est0 = est.astype(np.float64).copy()
     assert f(L, ROW_UPDATE, _p(s_in), _p(out), None, _p(est), _p(norm), ny, nx, frames, 0) == 0
     want = est0 * np.maximum(e, 0) / norm.astype(np.float64)
+    assert max_rel(est, want) < (1e-12 if sfx == 'f64' else 2e-6)
+    assert max_rel(out, np.fft.fft(padded(want), axis=2)) < tol
+    # the same two modes on `ratio - 1` (RowParams::sub_one): the stored spectrum is rowFFT(ratio - 1), the update
+    # factor max(1 + z / norm, 0)
+    emu.emu_set_sub_one.argtypes = [ctypes.c_int]
+    try:
+        emu.emu_set_sub_one(1)
+        assert f(L, ROW_RATIO, _p(s_pos), _p(out), _p(meas), None, None, ny, nx, frames, 0) == 0
+        assert max_rel(out, np.fft.fft(padded(meas.astype(np.float64) / zpos - 1.0), axis=2)) < (1e-11 if sfx == 'f64' else 3e-5)
+        est[...] = est0.astype(rt)
+        assert f(L, ROW_UPDATE, _p(s_in), _p(out), None, _p(est), _p(norm), ny, nx, frames, 0) == 0
+    finally:
+        emu.emu_set_sub_one(0)
+    want = est0 * np.maximum(1.0 + e / norm.astype(np.float64), 0)
     assert max_rel(est, want) < (1e-12 if sfx == 'f64' else 2e-6)
     assert max_rel(out, np.fft.fft(padded(want), axis=2)) < tol

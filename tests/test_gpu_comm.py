@@ -1,7 +1,7 @@
 """Multi-GPU plumbing and the batch entry points of the C ABI on one MI355X: the RCCL communicator at
 world size 1 (a world of 2 cannot share one GPU: RCCL refuses duplicate devices; the N > 1 control flow
 is covered on CPU in test_sharding.py / test_bench_cli.py), rl_batch_run, the in-situ cycle timing, the
-fused Richardson-Lucy kernel, and launches of more than 65535 images."""
+and launches of more than 65535 images."""
 import os
 
 import numpy as np
@@ -81,29 +81,6 @@ def test_time_cycle_brackets_every_launch(lib, small):
     a = plan.estimate()
     plan.bench_cycles(5, 1, seed=1)
     assert np.array_equal(a, plan.estimate())
-
-
-def test_fused_rl_kernel_matches_the_four_launch_iteration(lib, golden, monkeypatch):
-    """RLSTED_FUSED=1: one persistent launch for all iterations (teams of workgroups per XCD).  The item
-    code is the four-launch path's; the two are separate compilations of it (fused-multiply-add
-    contraction may differ), so agreement is to rounding, not bit for bit."""
-    psf = [golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'][0]]
-    obj = np.kron(golden('objects')['astronaut'].astype(np.float64), np.ones((1, 4, 4)))[0]
-    B = 24
-    est = {}
-    monkeypatch.setenv('RLSTED_PAIR', '0')      # like with like: the fused kernel runs the per-frame item code
-    for fused in ('0', '1'):
-        monkeypatch.setenv('RLSTED_FUSED', fused)
-        plan = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
-        assert plan.strategy()['fused_rl'] == (fused == '1') and not plan.strategy()['frame_pairs']
-        plan.set_object(np.broadcast_to(obj, (B, 512, 512)), 5e10 * 16)
-        plan.simulate(seed=5)
-        plan.iterate(7)
-        plan.iterate(3)          # continues from the current estimate
-        est[fused] = plan.estimate()
-        del plan
-    assert np.isfinite(est['1']).all()
-    assert max_rel(est['1'], est['0']) < 3e-6
 
 
 def test_more_images_than_grid_y(lib):

@@ -18,7 +18,12 @@ from oracle import line_sted_oracle as orc
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-5          # BASELINE.json: <= 1e-5 relative, 20 RL iterations
-F32_PIXELWISE = 3e-4    # pixels above 1e-3 of the maximum: dark pixels carry the same absolute error
+F32_MARGIN = 3e-6       # what the f32 plans are held to at K = 20 since round 3 (measured 0.7 ... 1.0e-6: exact normaliser +
+                        # `ratio - 1` transforms, conv_kernels.hpp rl_ratio); the contract itself is asserted at K = 100
+F32_PIXELWISE = 3e-4    # pixels above 1e-3 of the maximum.  H(estimate)'s f32 transform error is white and proportional to the
+                        # frame's RMS, so `measurement / H(estimate)` is 1e3 times less exact in regions 1e-3 as bright; H_t blurs
+                        # that over the PSF, 20 iterations add up: 0.8 ... 2.3e-4 over the eight config-2 cases (the same in
+                        # rounds 1-2: the `ratio - 1` transforms cure H_t's own error, not H's)
 
 
 def pixelwise(a, b):
@@ -67,42 +72,47 @@ def test_config_2_cycle_vs_oracle(lib, dose_sets, astronaut512, dose, views, mod
     for _ in range(K):
         d.iterate()
     est, ref = plan.estimate()[1], d.estimate[0]
-    assert max_rel(est, ref) < F32_TOL, (key, max_rel(est, ref))
+    assert max_rel(est, ref) < F32_MARGIN, (key, max_rel(est, ref))
     assert pixelwise(est, ref) < F32_PIXELWISE, (key, pixelwise(est, ref))
 
 
-@pytest.mark.parametrize('size,tol', [(1024, F32_TOL), (2048, F32_TOL), (4096, F32_TOL)])
-def test_large_tiles_f32_vs_f64_plan_at_20_iterations(lib, golden, size, tol):
-    """f32 drifts from f64 by ~4-5e-7 of the maximum per RL iteration, linearly: the rounded twiddles and
-    PSF spectrum perturb the operator the same way every iteration (an exact division instead of v_rcp_f32
-    moves it by < 1 %: measured, tools/gpu/gpu_f32_error.py).  On white-noise objects after 20 iterations:
-    8.7e-6 at 512^2, 9.5e-6 at 1024^2, 8.2e-6 at 2048^2, 9.7e-6 at 4096^2 (profiles/r02/f32_drift_final.json) --
-    inside the 1e-5 contract at every size since the long column transforms run as outer-decimation steps
-    around the L = 576 core (before: 1.12e-5 at 2048^2).  f64 plans meet 1e-10 at every size."""
+@pytest.mark.parametrize('size', [1024, 2048, 4096])
+def test_large_tiles_f32_vs_f64_plan(lib, golden, size):
+    """White-noise objects (every frequency carries weight: the hardest input for f32), f32 against the f64 plan on the
+    same noisy measurement.  Rounds 1-2 drifted by ~4-5e-7 of the maximum per RL iteration (8.7e-6 ... 9.7e-6 at K = 20,
+    4.5e-5 at K = 100): the f32 transform path's rounding noise in the normaliser H_t(ones) and in H_t(ratio) was
+    multiplied into the estimate again every iteration.  With the normaliser from the PSFs' integral images and the
+    second half of the iteration on `ratio - 1` (conv_kernels.hpp rl_ratio) the same runs give 0.9 ... 1.0e-6 at K = 20
+    and 1.5 ... 1.7e-6 at K = 100 (profiles/r03/f32_error.json) -- the 1e-5 contract holds at BASELINE config 5's
+    100 iterations, with margin.  f64 plans meet 1e-10 at every size."""
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     obj = np.random.default_rng(4321 if size == 4096 else 1234).random((1, size, size)) * 255
     p64 = lib.DeconvPlan(psf, 1, size, size, dtype='f64')
     p64.set_object(obj, 5e10 * (size // 128) ** 2)
     p64.simulate(seed=9)
     noisy = p64.measurement()
-    p64.iterate(20)
-    ref = p64.estimate()[0]
-    del p64
     p32 = lib.DeconvPlan(psf, 1, size, size, dtype='f32')
     p32.set_object(obj, 5e10 * (size // 128) ** 2)
     p32.set_measurement(noisy)
-    p32.iterate(20)
-    err = max_rel(p32.estimate()[0], ref)
-    print('f32 vs f64 at %d^2, K = 20: %.3e' % (size, err))
-    assert err < tol, err
+    errs, done = {}, 0
+    for k in (20, 100) if size == 4096 else (20,):     # 4096^2, K = 100: BASELINE config 5's tile and iteration count
+        p64.iterate(k - done)
+        p32.iterate(k - done)
+        done = k
+        errs[k] = max_rel(p32.estimate()[0], p64.estimate()[0])
+    print('f32 vs f64 at %d^2: %s' % (size, errs))
+    assert errs[20] < F32_MARGIN, errs
+    if 100 in errs:
+        assert errs[100] < F32_TOL, errs                # the contract, at five times the iterations it is quoted for
+        assert errs[100] < 4 * errs[20], errs           # growth is sub-linear now (was 5x for 5x the iterations)
 
 
 @pytest.mark.parametrize('size', [2048, 4096])
 def test_frame_pairs_on_the_long_transforms(lib, golden, size, monkeypatch):
-    """L = 2304 / 4608 (one workgroup-synchronous row transform per workgroup): the frame-pair loop (RLSTED_PAIR=1; not the
-    default at these sizes) against the per-frame loop and against the f64 plan, two white-noise frames, K = 20.  White
-    noise is the hardest object for f32 (every frequency carries weight): the per-frame loop sits at 0.87 ... 1.02e-5 here,
-    the pair loop -- which lacks the averaging of the Hermitian split -- at 1.02 ... 1.11e-5."""
+    """L = 2304 / 4608 (one workgroup-synchronous row transform per workgroup): the frame-pair loop (the default for f32
+    single-view plans at every size since round 3) against the per-frame loop (RLSTED_PAIR=0) and against the f64 plan,
+    two white-noise frames, K = 20.  Rounds 1-2 kept pairs opt-in here because f32 had no margin left (0.87 ... 1.11e-5);
+    both loops now sit near 1e-6."""
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     obj = np.random.default_rng(size).random((2, size, size)) * 255
     p64 = lib.DeconvPlan(psf, 2, size, size, dtype='f64')
@@ -124,8 +134,105 @@ def test_frame_pairs_on_the_long_transforms(lib, golden, size, monkeypatch):
         del p32
     errs = {f: [max_rel(est[f][i], ref[i]) for i in range(2)] for f in est}
     print('f32 vs f64 at %d^2, K = 20, pairs / per frame: %s' % (size, errs))
-    assert max(errs['1']) < 1.25e-5 and max(errs['0']) < 1.25e-5, errs
-    assert np.mean(errs['1']) < 1.25 * np.mean(errs['0']), errs      # (measured +4 ... +19 %: why pairs are opt-in at these sizes)
-    assert max_rel(est['1'], est['0']) < 1e-5                       # two f32 roundings of the same arithmetic
+    assert max(errs['1']) < F32_MARGIN and max(errs['0']) < F32_MARGIN, errs
+    assert max_rel(est['1'], est['0']) < F32_MARGIN                 # two f32 roundings of the same arithmetic
     monkeypatch.delenv('RLSTED_PAIR')
-    assert not lib.DeconvPlan(psf, 2, size, size, dtype='f32').strategy()['frame_pairs']   # default: per frame
+    assert lib.DeconvPlan(psf, 2, size, size, dtype='f32').strategy()['frame_pairs']   # default: pairs
+
+
+def test_frame_pairs_need_partners_of_comparable_brightness(lib, golden, astronaut512, monkeypatch):
+    """A pair's two frames share one complex transform, so f32 rounding error scales with the BRIGHTER partner:
+    the plan pairs frames only while every pair's levels are within a factor of 4 (RLSTED_PAIR_MAX_RATIO) and runs its
+    per-frame loop otherwise.  Frame 1 is 1e4 times dimmer than frame 0 here; frames 2 / 3 differ by 2."""
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    objs = np.stack([astronaut512] * 4)
+    levels = [8e11, 8e7, 8e11, 4e11]
+    ref = lib.DeconvPlan(psf, 4, 512, 512, dtype='f64')
+    ref.set_object(objs, levels)
+    ref.simulate(seed=21)
+    noisy = ref.measurement()
+    ref.iterate(20)
+    r = ref.estimate()
+    errs = {}
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv('RLSTED_PAIR_MAX_RATIO', '1e30')     # pair whatever the levels (what round 2 did)
+        plan = lib.DeconvPlan(psf, 4, 512, 512, dtype='f32')
+        assert plan.strategy()['frame_pairs']                       # the plan holds the pair loop ...
+        plan.set_object(objs, levels)
+        plan.set_measurement(noisy)
+        assert plan.strategy()['frame_pairs'] == force              # ... and does not run it on this batch
+        plan.iterate(20)
+        errs[force] = [max_rel(plan.estimate()[f], r[f]) for f in range(4)]
+    print('guarded / forced pairs, per frame:', errs)
+    assert max(errs[False]) < F32_MARGIN, errs
+    assert errs[True][1] > 10 * errs[False][1], errs                # the dim partner pays for the bright one when forced
+    monkeypatch.delenv('RLSTED_PAIR_MAX_RATIO')
+    ok = lib.DeconvPlan(psf, 4, 512, 512, dtype='f32')              # comparable partners stay paired
+    ok.set_object(objs, [8e11, 4e11, 2e11, 6e11])
+    ok.simulate(seed=3)
+    assert ok.strategy()['frame_pairs']
+
+
+# ---------------------------------------------------------------- BASELINE config 4: the full figure-2 sweep
+def test_config_4_full_figure_2_sweep(lib, golden):
+    """4 test objects x 6 doses x 3 scan modes (point-descan, line-descanned, line-rescanned) x 16 seeds = 1152 tasks
+    (line_sted_figure_2.py:39-56,77-162), K = 20, f32, on one GPU through sweep.figure_2_sweep -- the 18 PSF sets are the
+    product's own (tune_psf, psf_report, spline rotations on the device: 1 ... 10 views).  Three spot frames against
+    the oracle on the device-drawn measurement; the sharded form of the same call is tests/test_sharding.py (gloo)."""
+    from rescan_line_sted_amd import psf, sweep
+    objs = golden('objects')
+    objects = {n: objs[n][0].astype(np.float64) for n in ('astronaut', 'cat', 'lines', 'rings')}
+    doses = ('1p0x', '1p5x', '2p0x', '2p5x', '3p0x', '4p0x')
+    sets, _ = psf.figure_2_psfs([d + s for d in doses for s in ('_ld', '_lr')])
+    psf_sets = {}
+    for d in doses:
+        psf_sets[d + '_point'] = [np.asarray(p) for p in sets[d + '_lr_point_sted']]
+        for s in ('_ld', '_lr'):
+            key = [k for k in sets if k.startswith(d + s + '_line_')]
+            assert len(key) == 1
+            psf_sets[d + s] = [np.asarray(p) for p in sets[key[0]]]
+    assert sorted(len(v) for v in psf_sets.values()) == sorted([1] * 6 + [1, 3, 4, 6, 8, 10] + [2, 3, 4, 6, 8, 10])
+    K = 20
+    tasks, est = sweep.figure_2_sweep(objects, psf_sets, seeds=range(16), iterations=K, dtype='f32')
+    assert len(tasks) == 1152 and len(est) == 1152
+    assert all(np.isfinite(e).all() and e.min() >= 0 for e in est)
+    ids = sweep.object_ids(objects)
+    for i in (5, 700, 1151):                           # a point task, a mid-sweep line task, the last (10-view) one
+        o, p, seed = tasks[i]
+        ny, nx = objects[o].shape
+        alone = lib.DeconvPlan(psf_sets[p], 1, ny, nx, dtype='f32')      # the task's measurement: its Philox key is (seed, object id),
+        alone.set_object(objects[o][None], 5e10)                         # whatever it was batched with
+        alone.simulate_keyed([seed], [ids[o]])
+        noisy = alone.measurement()[0]
+        d = orc.Deconvolver(psf_sets[p])
+        d.noisy_measurement = [m[None] for m in noisy]
+        for _ in range(K):
+            d.iterate()
+        assert est[i].shape == (ny, nx)
+        assert max_rel(est[i], d.estimate[0]) < F32_MARGIN, (tasks[i], max_rel(est[i], d.estimate[0]))
+
+
+# ---------------------------------------------------------------- BASELINE config 5: 4096^2, K = 100, fp32 vs 16-bit spectra
+def test_config_5_tolerance_study(lib, tmp_path):
+    """4096 x 4096 tile, 100 RL iterations, the f32 plan and the two 16-bit-spectrum study builds (`_build --variant
+    q16 / qbf16`, built by __graft_entry__.build()) against the f64 plan: tools/gpu/gpu_tolerance_study.py, one process
+    per library.  f32 stays inside the contract all the way; spectra rounded to fp16 / bf16 between the row and the
+    column kernels leave it in the first iteration -- the study's finding, asserted here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'study.json')
+    subprocess.check_call([sys.executable, os.path.join(root, 'tools', 'gpu', 'gpu_tolerance_study.py'), '4096', '100', out])
+    study = json.load(open(out))
+    f32 = {r['iteration']: r['max_over_max'] for r in study['f32']}
+    assert f32[20] < F32_MARGIN and f32[100] < F32_TOL, f32
+    for mode in ('fp16_spectra', 'bf16_spectra'):
+        assert isinstance(study[mode], list), 'study build missing: %r (run __graft_entry__.build())' % (study[mode],)
+        q = {r['iteration']: r['max_over_max'] for r in study[mode]}
+        assert q[1] > 10 * F32_TOL and q[20] > 100 * F32_TOL, (mode, q)   # three to four orders outside the contract
+    keep = os.path.join(root, 'gpurun_out', 'r03')
+    os.makedirs(keep, exist_ok=True)
+    json.dump(study, open(os.path.join(keep, 'tolerance_study_4096.json'), 'w'), indent=1)

@@ -207,14 +207,13 @@ def test_many_frames_persistent_column_kernel_orders(lib, golden):
 
 @pytest.mark.parametrize('dtype,tol', [('f32', F32_TOL), ('f64', F64_TOL)])
 def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatch):
-    """The RL loop has switchable kernel flavours (read from the environment when a plan is
-    made): streaming = persistent prefetching column / RATIO / UPDATE kernels (RLSTED_STREAM bit
-    mask), in place = single-view iterations entirely in spec_a (RLSTED_INPLACE), the batch cut
-    into slices (RLSTED_CHUNK_MB) that are iterated on RLSTED_LANES concurrent streams.  Every
-    combination must give the default's result (same arithmetic, schedule and buffers differ;
-    only the compiler's fma contraction may differ between two instantiations) and the oracle's.
-    B = 19 frames of 512x512: several work items per persistent workgroup, an item count that is
-    not a multiple of 8 (fallback work order), odd frame count."""
+    """The RL loop has switchable schedules (read from the environment when a plan is made): in place = single-view
+    iterations entirely in spec_a (RLSTED_INPLACE; 0 also means the per-frame loop instead of frame pairs), the batch
+    cut into slices (RLSTED_CHUNK_MB) that are iterated on RLSTED_LANES concurrent streams, the column kernel's tile
+    order (RLSTED_COL_ORDER), frame pairs on / off.  Every combination must give the default's result (same arithmetic,
+    schedule and buffers differ; only the compiler's fma contraction may differ between two instantiations) and the
+    oracle's.  B = 19 frames of 512x512: an item count that is not a multiple of 8 (fallback work order), an odd
+    frame count (the last pair half empty)."""
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     rng = np.random.default_rng(5)
     B, K = 19, 6
@@ -225,15 +224,14 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
         d.iterate()
     results = {}
     noisy = None
-    # (streaming mask, in place, concurrent slice streams, slice budget in MB: 10 MB = 3 frames)
-    for stream, inplace, lanes, mb in (('0', '1', '2', '108'), ('7', '1', '2', '108'), ('7', '0', '1', '10'),
-                                       ('0', '0', '2', '10'), ('5', '1', '4', '10'), ('2', '0', '3', '20'),
+    # (frame pairs, in place, concurrent slice streams, slice budget in MB: 10 MB = 3 frames)
+    for stream, inplace, lanes, mb in (('0', '1', '2', '108'), ('1', '1', '2', '108'), ('0', '0', '1', '10'),
+                                       ('1', '1', '4', '10'), ('0', '0', '3', '20'), ('1', '1', '1', '100000'),
                                        ('0', '1', '1', '100000')):
-        # the streaming column kernel multiplies by the complex PSF spectrum: compare like with like (the
-        # real multiplier of the tiled kernel is a separate compilation with its own fma contraction)
+        # (the complex PSF-spectrum multiplier throughout: the real one is a separate compilation with its own fma contraction)
         monkeypatch.setenv('RLSTED_REAL_PSF', '0')
         monkeypatch.setenv('RLSTED_COL_ORDER', {'10': '3', '100000': '64'}.get(mb, '1'))   # image blocks of the tile order
-        monkeypatch.setenv('RLSTED_STREAM', stream)
+        monkeypatch.setenv('RLSTED_PAIR', stream)
         monkeypatch.setenv('RLSTED_INPLACE', inplace)
         monkeypatch.setenv('RLSTED_LANES', lanes)
         monkeypatch.setenv('RLSTED_CHUNK_MB', mb)
@@ -252,7 +250,7 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
     for key, est in results.items():
         assert max_rel(est, ref) < (2e-6 if dtype == 'f32' else 1e-13), key
     # default plans: real multiplier for the (point-symmetric) PSF spectrum, first iteration from the shared H(1)
-    for k in ('RLSTED_REAL_PSF', 'RLSTED_STREAM', 'RLSTED_INPLACE', 'RLSTED_LANES', 'RLSTED_CHUNK_MB', 'RLSTED_COL_ORDER'):
+    for k in ('RLSTED_REAL_PSF', 'RLSTED_PAIR', 'RLSTED_INPLACE', 'RLSTED_LANES', 'RLSTED_CHUNK_MB', 'RLSTED_COL_ORDER'):
         monkeypatch.delenv(k, raising=False)
     plan = lib.DeconvPlan(psf, B, 512, 512, dtype=dtype)
     plan.set_object(objs, 8e11)
@@ -262,19 +260,20 @@ def test_kernel_flavours_agree(lib, golden, astronaut512, dtype, tol, monkeypatc
     assert max_rel(plan.estimate(), ref) < (4e-6 if dtype == 'f32' else 1e-12)
 
 
-@pytest.mark.parametrize('lanes,mb,ahead', [('1', '100000', '0'), ('2', '10', '0'), ('3', '7', '1'), ('2', '10', '1')])
-def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lanes, mb, ahead, monkeypatch):
+@pytest.mark.parametrize('B,K', [(11, 4), (12, 5)])
+@pytest.mark.parametrize('lanes,mb', [('1', '100000'), ('2', '10'), ('3', '7')])
+def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lanes, mb, B, K, monkeypatch):
     """bench.py's timed call (rl_deconv_bench_cycles: forward model, Poisson, est = 1 and K
     iterations per slice of the batch, slices on concurrent streams) leaves exactly what
-    rl_deconv_simulate + rl_deconv_iterate over the whole batch leave."""
+    rl_deconv_simulate + rl_deconv_iterate over the whole batch leave.  Frame pairs (B = 11: the last pair half empty),
+    the last iteration's spectrum dropped (K = 5), lane joins deferred between the cycles -- the path bench.py times."""
     monkeypatch.setenv('RLSTED_LANES', lanes)
     monkeypatch.setenv('RLSTED_CHUNK_MB', mb)
-    monkeypatch.setenv('RLSTED_SIM_AHEAD', ahead)       # simulation of all slices on a stream of its own
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     rng = np.random.default_rng(17)
-    B, K = 11, 4
     objs = np.concatenate([astronaut512, rng.random((B - 1, 512, 512)) * 200])
     a = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
+    assert a.strategy()['frame_pairs']               # (an odd batch leaves its last pair half empty)
     a.set_object(objs, 8e11)
     a.bench_cycles(K, 3, seed=39)                      # three cycles back to back (no lane join in between): seeds 39, 40, 41; the last one stays
     b = lib.DeconvPlan(psf, B, 512, 512, dtype='f32')
@@ -461,8 +460,7 @@ def test_frame_pair_loop_equals_per_frame_loop(lib, ny, nx, B, monkeypatch):
         monkeypatch.setenv('RLSTED_PAIR', flag)
         plan = lib.DeconvPlan(psf, B, ny, nx, dtype='f64')
         info = plan.info()                   # pairs exist where both transforms are one-per-wave: L = 256, 576
-        fits = (B + 1) // 2 * info['lx'] <= B * info['pitch']      # odd batches: the half-empty last pair must fit the buffers
-        assert plan.strategy()['frame_pairs'] == (flag == '1' and info['ly'] in (256, 576) and info['lx'] in (256, 576) and fits)
+        assert plan.strategy()['frame_pairs'] == (flag == '1' and info['ly'] in (256, 576) and info['lx'] in (256, 576))
         plan.set_object(x, 1e7)
         plan.simulate(seed=3)
         plan.iterate(5)                      # a run of >= 4: its last iteration leaves no spectrum of the estimate behind ...
@@ -486,8 +484,7 @@ def test_frame_pair_loop_equals_per_frame_loop(lib, ny, nx, B, monkeypatch):
 
 def test_frame_pair_loop_f32_within_contract(lib, golden, astronaut512, monkeypatch):
     """f32: the pair loop is as accurate as the per-frame loop (same transforms, the packing / splitting arithmetic
-    gone): inside the contract on the BASELINE object; on white noise f32 sits at 0.8 ... 1.0e-5 after 20 iterations
-    either way (frame by frame the two loops differ by +-20 %, on average by nothing)."""
+    gone), BASELINE object and white noise alike, a factor of three inside the contract after 20 iterations."""
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     noise = np.random.default_rng(5).random((2, 512, 512)) * 200
     objs = np.concatenate([astronaut512, astronaut512.transpose(0, 2, 1), noise])
@@ -505,30 +502,6 @@ def test_frame_pair_loop_f32_within_contract(lib, golden, astronaut512, monkeypa
         plan.set_measurement(noisy)
         plan.iterate(20)
         err[flag] = [max_rel(plan.estimate()[f], ref.estimate()[f]) for f in range(4)]
-        assert max(err[flag][:2]) < F32_TOL, (flag, err[flag])
-    assert max(err['1'] + err['0']) < 1.1e-5, err                       # white noise: at the edge of the contract either way
-    assert np.mean(err['1']) < 1.1 * np.mean(err['0']), err
-
-
-@pytest.mark.parametrize('ny,nx,B,V', [(190, 203, 4, 3), (511, 300, 2, 2), (512, 512, 6, 4)])
-def test_frame_pair_loop_multi_view(lib, ny, nx, B, V, monkeypatch):
-    """Frame pairs in a multi-view plan (views summed in the column pass, RLSTED_FUSE_VIEWS: the f32 default): the V view
-    images of a pair are complex images too; same estimates as the per-frame loop with the same view fusion."""
-    rng = np.random.default_rng(ny + V)
-    psfs = [(rng.random((1, 9, 12)) + 0.02) for _ in range(V)]
-    x = rng.random((B, ny, nx)) * 40
-    monkeypatch.setenv('RLSTED_FUSE_VIEWS', '1')
-    out = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('RLSTED_PAIR', flag)
-        plan = lib.DeconvPlan(psfs, B, ny, nx, dtype='f64')
-        assert plan.strategy()['frame_pairs'] == (flag == '1')
-        plan.set_object(x, 1e7)
-        plan.simulate(seed=3)
-        plan.iterate(4)
-        a = plan.estimate()
-        plan.adjoint(rng.random((B, V, ny, nx)))          # clobbers the spectra
-        plan.iterate(2)
-        out[flag] = (a, plan.estimate(), plan.measurement(), plan.noiseless())
-    assert np.array_equal(out['1'][2], out['0'][2]) and np.array_equal(out['1'][3], out['0'][3])
-    assert max_rel(out['1'][0], out['0'][0]) < 1e-12 and max_rel(out['1'][1], out['0'][1]) < 1e-12
+    print('pairs / per frame:', err)
+    assert max(err['1'] + err['0']) < 3e-6, err                         # measured 0.7 ... 0.9e-6 (round 2: 0.75 ... 1.0e-5)
+    assert np.mean(err['1']) < 1.25 * np.mean(err['0']), err

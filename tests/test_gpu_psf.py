@@ -7,6 +7,8 @@ fitted widths 1e-6: the restated MINPACK iteration stops (like the reference's) 
 ~1e-6 short of the minimum, so 1-ulp input differences (device exp2 vs numpy power) can move it that far;
 tune_psf 1e-6 (Brent amplifies rounding-level differences of its objective).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -94,9 +96,14 @@ def test_get_width(st, golden):
         assert max_rel(f, fit[:n]) < 1e-7
 
 
-@pytest.mark.parametrize('name,which', [('1p5x_ld', 'point'), ('2p0x_lr', 'point'), ('1p5x_lr', 'line'),
-                                        ('1p0x_ld', 'line'), ('2p0x_lr', 'line')])
+G3_POINTS = [d + s for d in ('1p0x', '1p5x', '2p0x', '2p5x', '3p0x', '4p0x') for s in ('_ld', '_lr')]
+
+
+@pytest.mark.parametrize('which', ['point', 'line'])
+@pytest.mark.parametrize('name', G3_POINTS)
 def test_g3_tune_psf_matches_reference(st, golden, name, which):
+    """All twelve figure-2 operating points (line_sted_figure_2.py:77-162), point and line tuning each, on the device
+    against what the reference's tune_psf returned (G3)."""
     g = golden('g3_tune_psf')
     pr, lr, pe, le, nori, maxexc, resc = g[name + '/inputs']
     if which == 'point':
@@ -149,8 +156,10 @@ def test_rotate_matches_reference_psf_sets(st, golden):
         a = rng.random(shape)
         for deg in (45, 60, 22.5, 135, 120, 0, 90):
             assert max_rel(psf.rotate(a, deg), orc.rotate(a, deg)) < 1e-12, (shape, deg)
-    g3, g8 = golden('g3_tune_psf'), golden('g8_fig2_psfs')
-    for name in ('1p0x_ld', '1p5x_lr', '2p0x_lr'):
+    g3 = golden('g3_tune_psf')
+    # G8: three operating points; G8b: the two remaining line-rescan doses of BASELINE config 2 (6 and 8 orientations)
+    for name in ('1p0x_ld', '1p5x_lr', '2p0x_lr', '2p5x_lr', '3p0x_lr'):
+        g8 = golden('g8_fig2_psfs' if name + '/point' in golden('g8_fig2_psfs') else 'g8b_fig2_psfs_more')
         pr, lr, pe, le, nori, maxexc, resc = g3[name + '/inputs']
         c = psf.psf_comparison_pair(pr, lr, pe, le, 'rescanned' if resc else 'descanned', int(nori),
                                     max_excitation_brightness=float(maxexc))
@@ -316,3 +325,29 @@ def test_psf_report_batch_figure_1_sweep_time_and_golden(golden):
             for k, i in (('excitation_dose', 2), ('depletion_dose', 3), ('expected_emission', 4)):
                 assert abs(r[k] - sc[i]) <= 1e-9 * max(abs(sc[i]), 1e-30), (p, k)
     assert hits >= 20
+
+
+def test_psf_report_output_dir_writes_the_reference_file_set(st, golden, tmp_path):
+    """psf_report / generate_psfs(output_dir=...) (ref:311-346): the same nine (line) / five (point) file names as the
+    reference, including emission_psf.tif and sted_psf_line_rescan_unscaled.tif (rl_psf_generate_line_extras), whose
+    contents match what the reference wrote (G1b; float32 on disk) and the oracle."""
+    from rescan_line_sted_amd import np_tif
+    g = golden('g1b_line_dumps')
+    exc, dep, steps, pulses = g['args']
+    out = str(tmp_path / 'line')
+    st.psf_report('line', float(exc), float(dep), float(steps), float(pulses), verbose=False, output_dir=out)
+    assert sorted(os.listdir(out)) == [str(f) for f in g['files']]
+    for name in ('emission_psf.tif', 'sted_psf_line_rescan_unscaled.tif', 'sted_psf_line_rescan.tif'):
+        got = np_tif.tif_to_array(os.path.join(out, name))
+        assert got.shape == g[name].shape and got.dtype == np.float32
+        assert max_rel(got, g[name]) < 1e-6, name
+    sigma = steps / (2 * np.sqrt(2 * np.log(2)))
+    n = 1 + 2 * int(np.round(5 * sigma))
+    p = orc.generate_psfs((1, n, n), exc, dep, sigma, psf_type='line', with_intermediates=True)
+    from rescan_line_sted_amd import psf
+    extras = psf._line_extras(n, n, exc, dep, sigma, p['line_rescan_ratio'])
+    assert max_rel(extras['emission_psf.tif'], p['emission_psf']) < 1e-13
+    assert max_rel(extras['sted_psf_line_rescan_unscaled.tif'], p['rescan_sted_unscaled']) < 1e-12
+    out = str(tmp_path / 'point')
+    st.generate_psfs((1, 27, 27), 0.25, 9.0, 3.4, psf_type='point', output_dir=out, verbose=False)
+    assert len(os.listdir(out)) == 5

@@ -148,11 +148,12 @@ def test_spline_rotate_restates_scipy():
             assert np.abs(orc.spline_rotate(a, deg) - ref).max() < 1e-12, (shape, deg)
 
 
-@pytest.mark.parametrize('name', ['1p0x_ld', '1p5x_lr', '2p0x_lr'])
+@pytest.mark.parametrize('name', ['1p0x_ld', '1p5x_lr', '2p0x_lr', '2p5x_lr', '3p0x_lr'])
 def test_g8_fig2_psf_sets(golden, name):
     """psf_comparison_pair (tune_psf x2, fine psf_report x2, normalisation, rotation)
-    against the PSF sets the reference's figure-2 script produced."""
-    g3, g8 = golden('g3_tune_psf'), golden('g8_fig2_psfs')
+    against the PSF sets the reference's figure-2 script produced (G8; G8b: the 2.5x / 3.0x line-rescan sets)."""
+    g3 = golden('g3_tune_psf')
+    g8 = golden('g8_fig2_psfs' if name + '/point' in golden('g8_fig2_psfs') else 'g8b_fig2_psfs_more')
     pr, lr, pe, le, nori, maxexc, resc = g3[name + '/inputs']
     c = orc.psf_comparison_pair(pr, lr, pe, le, 'rescanned' if resc else 'descanned', int(nori),
                                 max_excitation_brightness=maxexc)
@@ -186,3 +187,17 @@ def test_map_coordinates_restates_scipy():
     ys, xs = rng.uniform(-2, 25, 300), rng.uniform(-2, 33, 300)
     ys[:4], xs[:4] = [0, 22, 22, 0], [0, 30, 0, 30]                 # the corners are inside
     assert np.abs(orc.map_coordinates_cubic(a, ys, xs) - map_coordinates(a, [ys, xs])).max() < 1e-13
+
+
+def test_g1b_line_dump_intermediates(golden):
+    """The two arrays generate_psfs(output_dir=...) writes that are not in its return value (ref:339-341), against the
+    TIFs the reference wrote (float32 on disk)."""
+    g = golden('g1b_line_dumps')
+    exc, dep, steps, pulses = g['args']
+    sigma = steps / (2 * np.sqrt(2 * np.log(2)))
+    n = 1 + 2 * int(np.round(5 * sigma))
+    p = orc.generate_psfs((1, n, n), exc, dep, sigma, psf_type='line', with_intermediates=True)
+    assert p['rescan_sted_unscaled'].shape == g['sted_psf_line_rescan_unscaled.tif'].shape
+    assert max_rel(p['emission_psf'], g['emission_psf.tif']) < 1e-7
+    assert max_rel(p['rescan_sted_unscaled'], g['sted_psf_line_rescan_unscaled.tif']) < 1e-7
+    assert max_rel(p['rescan_sted'], g['sted_psf_line_rescan.tif']) < 1e-7

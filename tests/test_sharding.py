@@ -124,3 +124,27 @@ def test_unique_id_rendezvous_by_file(tmp_path):
     for p in procs:
         p.join()
     assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
+
+
+def test_rendezvous_file_is_private_fresh_and_keyed_by_the_launch(tmp_path, monkeypatch):
+    """VERDICT r02 / ADVICE: the id file sits in a 0700 directory of this user, its name carries the launcher's pid AND
+    start time (a recycled pid, or a crashed earlier launch with the same port, gives another name), the communicator
+    sequence number and the port; rank 0 never hands out a file it did not write (a stale one is removed first) and
+    creates its own exclusively with mode 0600."""
+    import stat
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(tmp_path))
+    monkeypatch.setenv('MASTER_PORT', '29999')
+    d = sharding.rendezvous_dir()
+    assert d.startswith(str(tmp_path)) and stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    p0, p1 = sharding.rendezvous_path(seq=0), sharding.rendezvous_path(seq=1)
+    assert p0 != p1 and os.path.dirname(p0) == d and '_29999_' in os.path.basename(p0)
+    start = open('/proc/%d/stat' % os.getppid()).read().rsplit(')', 1)[1].split()[19]
+    assert os.path.basename(p0).startswith('rccl_%d_%s_' % (os.getppid(), start))
+    monkeypatch.setenv('MASTER_PORT', '30000')
+    assert sharding.rendezvous_path(seq=0) != p0
+    with open(p0, 'wb') as f:                      # a stale id of the right size
+        f.write(b'\xff' * 128)
+    fresh = bytes(range(128))
+    assert sharding.exchange_unique_id(0, lambda: fresh, path=p0) == fresh
+    assert open(p0, 'rb').read() == fresh and stat.S_IMODE(os.stat(p0).st_mode) == 0o600
+    assert sharding.exchange_unique_id(1, None, path=p0, timeout=5) == fresh

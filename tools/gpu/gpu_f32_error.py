@@ -14,7 +14,7 @@ for size in (512, 1024, 2048):
     p32 = _lib.DeconvPlan(psf, 1, size, size, dtype='f32'); p32.set_object(obj, 5e10 * (size // 128) ** 2); p32.set_measurement(noisy)
     errs = {}
     done = 0
-    for k in (1, 5, 20):
+    for k in (1, 5, 20, 100):
         p64.iterate(k - done); p32.iterate(k - done); done = k
         a, b = p32.estimate()[0], p64.estimate()[0]
         errs[k] = float(np.abs(a - b).max() / b.max())
@@ -28,4 +28,5 @@ plan.bench_cycles(20, 1, seed=1)
 t0 = time.perf_counter(); plan.bench_cycles(20, 10, seed=2); el = time.perf_counter() - t0
 out['frames_per_s'] = 2560 / el
 print(out['frames_per_s'])
-json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r02', 'f32err_%s.json' % out['tag']), 'w'))
+os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r03'), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r03', 'f32err_%s.json' % out['tag']), 'w'))

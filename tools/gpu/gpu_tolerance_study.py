@@ -8,7 +8,7 @@ conv_kernels.hpp RL_SPEC_QUANT): they measure the numerical effect of 16-bit spe
 and the column kernels, not its bandwidth.  Each build runs in a process of its own (RLSTED_LIB); the float64
 checkpoints travel through /tmp.
 
-    python tools/gpu/gpu_tolerance_study.py [n] [K]      -> gpurun_out/r02/tolerance_study_<n>.json
+    python tools/gpu/gpu_tolerance_study.py [n] [K] [out.json]      (default gpurun_out/r03/tolerance_study_<n>.json)
 """
 import json
 import os
@@ -86,8 +86,9 @@ def main():
         subprocess.check_call([sys.executable, os.path.abspath(__file__), '--worker', mode, str(n), str(K), tmp], env=env)
         if mode != 'f64':
             out[mode] = json.load(open(os.path.join(tmp, 'rows_%s.json' % mode)))
-    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r02'), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r02', 'tolerance_study_%d.json' % n), 'w'), indent=1)
+    dest = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'gpurun_out', 'r03', 'tolerance_study_%d.json' % n)
+    os.makedirs(os.path.dirname(os.path.abspath(dest)), exist_ok=True)
+    json.dump(out, open(dest, 'w'), indent=1)
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
