@@ -187,8 +187,9 @@ int rl_comm_allreduce_max(rl_comm* c, double* value);
  * rl_deconv_device_ptr) on `root`, rank-major, straight from the device buffers: every rank sends
  * to the root, the root receives on all its links at once.  rl_gather delivers float64 on the
  * root's host (host_out: sum(counts) frames; ignored on other ranks); rl_gather_device leaves the
- * result in a device buffer owned by the communicator (root: *dev_out, valid until the next gather;
- * other ranks: NULL) in the plan's dtype.                                                */
+ * result in a device buffer owned by the communicator (root: *dev_out, valid until the next
+ * rl_gather / rl_gather_device of this communicator -- rl_comm_gather_host stages through a buffer of its own and
+ * leaves it alone; other ranks: NULL) in the plan's dtype.                                 */
 int rl_gather(rl_comm* c, rl_deconv* plan, int which, int root, const int* counts, double* host_out);
 int rl_gather_device(rl_comm* c, rl_deconv* plan, int which, int root, const int* counts, void** dev_out,
                      size_t* n_elements, int* dtype);

@@ -65,6 +65,8 @@ def jobs():
 VARIANTS = {   # study builds: librlsted_<name>.so beside the product library (python -m ..._build --variant NAME)
     'q16': ['-DRL_SPEC_QUANT=1'],     # spectra rounded to IEEE half on their way to memory (BASELINE config 5 study)
     'qbf16': ['-DRL_SPEC_QUANT=2'],   # ... to bfloat16
+    'ab1': os.environ.get('RL_AB1', '').split(),   # scratch A/B builds (development): flags from the environment
+    'ab2': os.environ.get('RL_AB2', '').split(),
 }
 
 

@@ -33,18 +33,23 @@ struct Rccl {
     std::string error;
 };
 
-Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
+static void rccl_load(Rccl& r);
+Rccl* rccl() {   // loaded once, whichever thread asks first (function-local static: initialisation is thread safe)
+    static Rccl r = [] {
+        Rccl x;
+        rccl_load(x);
+        return x;
+    }();
+    return &r;
+}
+static void rccl_load(Rccl& r) {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.so) break;
     }
     if (!r.so) {
         r.error = std::string("cannot load librccl.so: ") + dlerror();
-        return &r;
+        return;
     }
 #define RL_SYM(field, sym)                                                  \
     r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, sym));       \
@@ -59,8 +64,27 @@ Rccl* rccl() {
     RL_SYM(AllReduce, "ncclAllReduce")
     RL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RL_SYM
-    return &r;
 }
+
+// ncclGroupStart ... ncclGroupEnd around a block of sends / receives.  The group is ALWAYS closed when the scope is
+// left, error returns included: an open group on this thread would swallow every later RCCL call.
+struct GroupScope {
+    Rccl* r;
+    bool open = false;
+    explicit GroupScope(Rccl* r_) : r(r_) {}
+    ncclResult_t start() {
+        const ncclResult_t rc = r->GroupStart();
+        open = rc == ncclSuccess;
+        return rc;
+    }
+    ncclResult_t end() {
+        open = false;
+        return r->GroupEnd();
+    }
+    ~GroupScope() {
+        if (open) (void)r->GroupEnd();
+    }
+};
 
 #define RCCL_TRY(expr)                                                                                       \
     do {                                                                                                     \
@@ -74,8 +98,10 @@ struct rl_comm {
     rl_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    void* gathered = nullptr;   // root: the last gather's result (device)
+    void* gathered = nullptr;   // root: the last plan gather's result (device); what rl_gather_device hands out
     size_t gathered_bytes = 0;
+    void* staging = nullptr;    // rl_comm_gather_host's own device staging (never aliases `gathered`)
+    size_t staging_bytes = 0;
     double* scalar = nullptr;   // device scratch for the reductions
 };
 
@@ -126,6 +152,7 @@ int rl_comm_destroy(rl_comm* c) {
     hipStreamSynchronize(c->ctx->stream);
     if (c->comm) rccl()->CommDestroy(c->comm);
     if (c->gathered) hipFree(c->gathered);
+    if (c->staging) hipFree(c->staging);
     if (c->scalar) hipFree(c->scalar);
     delete c;
     return RL_OK;
@@ -190,7 +217,8 @@ static int gather_impl(rl_comm* c, rl_deconv* plan, int which, int root, const i
             HIP_TRY(hipMalloc(&c->gathered, need ? need : 1));
             c->gathered_bytes = need;
         }
-        RCCL_TRY(r->GroupStart());
+        GroupScope group(r);
+        RCCL_TRY(group.start());
         size_t off = 0;
         for (int k = 0; k < c->world; ++k) {
             const size_t n = (size_t)counts[k] * per_frame;
@@ -202,13 +230,14 @@ static int gather_impl(rl_comm* c, rl_deconv* plan, int which, int root, const i
             }
             off += n;
         }
-        RCCL_TRY(r->GroupEnd());
+        RCCL_TRY(group.end());
     } else {
         const size_t n = (size_t)counts[c->rank] * per_frame;
         if (n) {
-            RCCL_TRY(r->GroupStart());
+            GroupScope group(r);
+            RCCL_TRY(group.start());
             RCCL_TRY(r->Send(src, n, nt, root, c->comm, s));
-            RCCL_TRY(r->GroupEnd());
+            RCCL_TRY(group.end());
         }
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -228,18 +257,19 @@ int rl_comm_gather_host(rl_comm* c, const double* local, const size_t* counts, i
     size_t total = 0;
     for (int k = 0; k < c->world; ++k) total += counts[k];
     const size_t need = (c->rank == root ? total : mine) * sizeof(double);
-    if (need > c->gathered_bytes) {
-        if (c->gathered) HIP_TRY(hipFree(c->gathered));
-        c->gathered = nullptr;
-        c->gathered_bytes = 0;
-        HIP_TRY(hipMalloc(&c->gathered, need ? need : 1));
-        c->gathered_bytes = need;
+    if (need > c->staging_bytes) {
+        if (c->staging) HIP_TRY(hipFree(c->staging));
+        c->staging = nullptr;
+        c->staging_bytes = 0;
+        HIP_TRY(hipMalloc(&c->staging, need ? need : 1));
+        c->staging_bytes = need;
     }
-    double* buf = (double*)c->gathered;
+    double* buf = (double*)c->staging;
     if (c->rank == root) {
         if (total && !out) return fail(RL_ERR_INVALID, "out is NULL on the root rank");
         size_t off = 0;
-        RCCL_TRY(r->GroupStart());
+        GroupScope group(r);
+        RCCL_TRY(group.start());
         for (int k = 0; k < c->world; ++k) {
             if (k == root) {
                 if (mine) HIP_TRY(hipMemcpyAsync(buf + off, local, mine * sizeof(double), hipMemcpyHostToDevice, s));
@@ -248,13 +278,14 @@ int rl_comm_gather_host(rl_comm* c, const double* local, const size_t* counts, i
             }
             off += counts[k];
         }
-        RCCL_TRY(r->GroupEnd());
+        RCCL_TRY(group.end());
         if (total) HIP_TRY(hipMemcpyAsync(out, buf, total * sizeof(double), hipMemcpyDeviceToHost, s));
     } else if (mine) {
         HIP_TRY(hipMemcpyAsync(buf, local, mine * sizeof(double), hipMemcpyHostToDevice, s));
-        RCCL_TRY(r->GroupStart());
+        GroupScope group(r);
+        RCCL_TRY(group.start());
         RCCL_TRY(r->Send(buf, mine, ncclDouble, root, c->comm, s));
-        RCCL_TRY(r->GroupEnd());
+        RCCL_TRY(group.end());
     }
     HIP_TRY(hipStreamSynchronize(s));
     return RL_OK;

@@ -515,47 +515,214 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
             }
         }
         inverse_classes(Y, p.out + (size_t)by * img);
-    } else if constexpr (MODE == COL_H_MULTI) {
-        // by = frame: ONE forward transform of the frame's spectrum, V products + inverse transforms (the radix-M
-        // butterfly is recomputed per view: M log M adds against keeping a second M x NV register set alive)
-        Regs Y, Z;
-        forward_classes(p.in + (size_t)by * img, Y, true);
-        for (int view = 0; view < p.V; ++view) {
-            if (colok) {
-                RL_FOR_LIVE_SLOTS(s) {
-                    cx<T> u[M];
-                    slot_spectrum(Y, s, view, u);
-                    slot_classes(u, s, Z);
-                }
-            }
-            inverse_classes(Z, p.out + ((size_t)by * p.V + view) * img);
+    } else {
+        static_assert(MODE == COL_PER_IMAGE, "the multi-view modes of the long transforms live in colconv_outer4_body");
+    }
+#undef RL_FOR_LIVE_SLOTS
+}
+
+// ---------------------------------------------------------------------------------------------
+// FOUR WAVES PER COLUMN (round 3; L = 4 * Li): wave g of a column owns residue class g on the image side and the
+// quarter j = g of the column spectrum, X[k + Li g], on the spectrum side; the radix-4 step is an all-to-all among
+// the column's four waves through LDS (each writes its 9 values per lane, reads the three others':  (-i)^(q g) are
+// sign flips and swaps).  Per wave ONE register set (9 complex values per lane) -- so COL_H_MULTI / COL_HT_SUM hold
+// their persistent quarter beside the working set (colconv_outer_body's multi-view modes needed two 4 x 10 sets per lane:
+// 256 registers + spills; a two-waves-per-column form, built and measured in round 3, still spilled 60-100 registers and
+// lost to V per-image launches: both removed) -- and per image ONE load phase and ONE store phase over whole tile rows
+// and 6 workgroup barriers (16 in colconv_outer_body).  Workgroup = 4 C waves (C = 4 columns: 1024 threads, 32-byte row
+// segments, one workgroup per CU), LDS = 4 C core regions.  Measured at 2048^2 (fft_configs.hpp OuterCol<2304>): the
+// per-image mode is 40 % SLOWER than colconv_outer_body (one workgroup per CU: its load, transform and store phases do not
+// overlap with another workgroup's), COL_HT_SUM + the single-spectrum ROW_UPDATE it allows beat V per-image launches by 21 %.
+template <class Cfg, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, class Sync>
+RL_HD void colconv_outer4_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    static_assert(Cfg::T == 64, "the core must be a wave-private transform");
+    constexpr int M = 4, NP = Cfg::NP, Li = Cfg::L, L = M * Li, LP = LdsSlots<Cfg>::value;
+    constexpr int NG = 64 * C;                           // threads of one class group: they move their class of the tile
+    static_assert((Li * C) % NG == 0, "a class tile must divide evenly over its group");
+    constexpr int NLD = (Li * C) / NG;
+    using FL = PassInfo<Cfg, false, NP - 1>;
+    using IL = PassInfo<Cfg, true, NP - 1>;
+    static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
+    constexpr int NV = FL::NBM * FL::R;                  // lane-local register slots of one core transform
+    constexpr int NS = NV + (FL::TAIL ? 1 : 0);          // ... and the tail element
+    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
+    constexpr int LIVE = FL::NBF < 64 ? FL::NBF : 64;    // lanes that hold values in the spectrum-side register layout
+    static_assert(NV <= VMAX && NS * LIVE <= LP, "a wave's LDS region must hold one register set");
+    constexpr int CTW = PassTw<Cfg, false, 0>::TOTAL;    // W_L^(q k) at tw[CTW + (q - 1) * Li + k]
+    const int w = rl_uniform(tid / 64), lane = tid % 64;
+    const int g = w / C, cw = w % C;                     // class / spectrum quarter, and column, of this wave
+    const int col0 = bx * C, col = col0 + cw;
+    const bool colok = col < p.kx;
+    const size_t img = spec_image_elems(p.ny, p.pitch);
+    LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
+    cx<T>* __restrict__ const mine = lds + w * LP;
+    cx<T>* __restrict__ const group_lds = lds + g * C * LP;      // the regions of this class group: its tile
+    const cx<T>* __restrict__ const column_lds = lds + cw * LP;  // the regions of this column: wave q's at + q * C * LP
+    const int th = tid - g * NG;
+    // the multi-view loops hand the lambdas a twiddle pointer the optimiser cannot see through, or it hoists every
+    // (view-invariant) twiddle load out of the view loop -- ~60 registers
+    auto launder = [](const cx<T>* q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(q));
+#endif
+        return q;
+    };
+
+    // class g of the tile: element e = th + it*NG <-> (m = e / C, column c = e % C), image row 4 m + g
+    auto load_class = [&](const cx<T>* __restrict__ in) {
+        cx<T> x[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = th + it * NG;
+            const int row = M * (e / C) + g, c = e % C;
+            x[it] = mk<T>((T)0, (T)0);
+            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
         }
-    } else {   // COL_HT_SUM: the V products are summed in the Fourier domain, one inverse transform (see colconv_wave_body)
-        Regs Y, A;
 #pragma unroll
-        for (int j = 0; j < M; ++j)
+        for (int it = 0; it < NLD; ++it) {
+            const int e = th + it * NG;
+            group_lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
+        }
+    };
+    auto store_class = [&](cx<T>* __restrict__ out) {
 #pragma unroll
-            for (int s = 0; s <= NV; ++s) A[j][s] = mk<T>((T)0, (T)0);
-        for (int view = 0; view < p.V; ++view) {
-            forward_classes(p.in + ((size_t)by * p.V + view) * img, Y, view == 0);
-            if (colok) {
-                RL_FOR_LIVE_SLOTS(s) {
-                    cx<T> u[M];
-                    slot_spectrum(Y, s, view, u);
+        for (int it = 0; it < NLD; ++it) {
+            const int e = th + it * NG;
+            const int row = M * (e / C) + g, c = e % C;
+            if (row < p.ny && col0 + c < p.kx)
+                out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(group_lds[c * LP + view_lds.nat(e / C)], p.qscale);
+        }
+    };
+    auto slot_index = [&](int s) -> int {   // element index (within the core transform) of register slot s; s == NV: the tail element
+        if (s == NV) return (64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF;
+        return (lane + (s / FL::R) * 64) + (s % FL::R) * FL::NBF;
+    };
+    auto slot_live = [&](int s) -> bool { return s == NV ? true : (lane + (s / FL::R) * 64) < FL::NBF; };
+#define RL_FOR_LIVE_SLOTS(s)                                  \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s)            \
+        if (slot_live(s))
+    // x * (-i)^n (forward) or (+i)^n (inverse), n = 0 .. 3 (wave uniform)
+    auto times_i_pow = [&](cx<T> x, int n, bool inv) -> cx<T> {
+        n &= 3;
+        if (n == 0) return x;
+        if (n == 2) return mk<T>(-x.re, -x.im);
+        return ((n == 1) != inv) ? rot90<false>(x) : rot90<true>(x);   // forward n = 1: -i; inverse n = 1: +i; n = 3: the other one
+    };
+    using Set = cx<T>[NS];
+
+    // Y <- W_L^(g k) * core transform of residue class g of image `in`.  Barriers: the caller's before the load (LDS
+    // free), one after it.
+    auto forward_class = [&](const cx<T>* __restrict__ in, Set& Y, const cx<T>* tw) {
+        load_class(in);
+        sync.wg();
+        cx<T> v[VMAX];
+        cx<T> tl = mk<T>((T)0, (T)0);
+        if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw, sync);
 #pragma unroll
-                    for (int j = 0; j < M; ++j) A[j][s] = A[j][s] + u[j];
+        for (int s = 0; s < NV; ++s) Y[s] = v[s];
+        if constexpr (FL::TAIL) Y[NV] = tl;
+        if (colok && g > 0) {
+            RL_FOR_LIVE_SLOTS(s) Y[s] = cmul(Y[s], tw[CTW + (g - 1) * Li + slot_index(s)]);
+        }
+    };
+    // all-to-all among the four waves of the column: R[s] <- sum_q (-+i)^(q g) S_q[s].  The wave's own region must be
+    // free of other readers (caller's barrier, or nothing when only this wave has used it since the last barrier).
+    auto all_to_all = [&](Set& S, bool inv) {
+        if (colok) {
+            sync.wave();   // (own region: the core transform's last LDS reads are done)
+            RL_FOR_LIVE_SLOTS(s) mine[s * LIVE + lane] = S[s];
+        }
+        sync.wg();
+        if (colok) {
+            // slot by slot, a compiler fence in between: left alone the scheduler issues all 4 x NS reads first and holds
+            // 72 registers for them -- enough to make the multi-view modes spill
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (slot_live(s)) {
+                    cx<T> acc = mk<T>((T)0, (T)0);
+#pragma unroll
+                    for (int q = 0; q < M; ++q) acc = acc + times_i_pow(column_lds[q * C * LP + s * LIVE + lane], q * g, inv);
+                    S[s] = acc;
                 }
+                if (s % 3 == 2) sync.wave();
             }
         }
+    };
+    // Z <- X * psf_hat[view] on this wave's quarter of the column spectrum (Z may be X)
+    auto multiply_into = [&](const Set& X, Set& Z, int view) {
+        const size_t pcol = ((size_t)view * p.kx + col) * L + (size_t)Li * g;
         if (colok) {
             RL_FOR_LIVE_SLOTS(s) {
-                cx<T> u[M];
-#pragma unroll
-                for (int j = 0; j < M; ++j) u[j] = A[j][s];
-                slot_classes(u, s, A);
+                if constexpr (REALP) Z[s] = scale(X[s], p.psf_hat_re[pcol + slot_index(s)]);
+                else Z[s] = cmul(X[s], p.psf_hat[pcol + slot_index(s)]);
             }
         }
-        inverse_classes(A, p.out + (size_t)by * img);
+    };
+    // X' (this wave's quarter) -> class g of the output image.  Barriers inside: before the exchange overwrites the
+    // region, after it, before the inverse transform overwrites it, before the store.
+    auto inverse_class = [&](Set& Z, cx<T>* __restrict__ out, const cx<T>* tw) {
+        sync.wg();                       // nobody reads this wave's region any more
+        all_to_all(Z, true);
+        if (colok && g > 0) {
+            RL_FOR_LIVE_SLOTS(s) {
+                const cx<T> t = tw[CTW + (g - 1) * Li + slot_index(s)];
+                Z[s] = cmul(Z[s], mk<T>(t.re, -t.im));
+            }
+        }
+        sync.wg();                       // the exchange has been read: the regions are free for the transforms
+        if (colok) {
+            cx<T> v[VMAX];
+#pragma unroll
+            for (int s = 0; s < NV; ++s) v[s] = Z[s];
+            cx<T> tl = mk<T>((T)0, (T)0);
+            if constexpr (FL::TAIL) tl = Z[NV];
+            run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw, sync);
+            sync.wave();   // last pass' LDS reads are done before the column is overwritten
+#pragma unroll
+            for (int nb = 0; nb < IL::NB; ++nb) {
+                const int j = lane + nb * 64;
+                if (j < IL::NBF) {
+#pragma unroll
+                    for (int rr = 0; rr < IL::R; ++rr) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), rr) = v[nb * IL::R + rr];
+                }
+            }
+        }
+        sync.wg();
+        store_class(out);
+    };
+
+    if constexpr (MODE == COL_PER_IMAGE) {
+        const int frame = by / p.V, view = by % p.V;
+        Set Y;
+        forward_class(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img, Y, p.tw);
+        all_to_all(Y, false);            // Y = X[k + Li g]
+        multiply_into(Y, Y, view);
+        inverse_class(Y, p.out + (size_t)by * img, p.tw);
+    } else if constexpr (MODE == COL_H_MULTI) {
+        // by = frame: ONE forward transform of the frame's spectrum (H, ref:573-576), V products + inverse transforms
+        Set X, Z;
+        forward_class(p.in + (size_t)by * img, X, p.tw);
+        all_to_all(X, false);
+        for (int view = 0; view < p.V; ++view) {
+            const cx<T>* tw = launder(p.tw);
+            multiply_into(X, Z, view);
+            inverse_class(Z, p.out + ((size_t)by * p.V + view) * img, tw);
+        }
+    } else {   // COL_HT_SUM: the V products are summed in the Fourier domain, one inverse transform (see colconv_wave_body)
+        Set Y, A;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) A[s] = mk<T>((T)0, (T)0);
+        for (int view = 0; view < p.V; ++view) {
+            const cx<T>* tw = launder(p.tw);
+            if (view > 0) sync.wg();     // the previous view's exchange has been read
+            forward_class(p.in + ((size_t)by * p.V + view) * img, Y, tw);
+            all_to_all(Y, false);
+            multiply_into(Y, Y, view);
+            if (colok) {
+                RL_FOR_LIVE_SLOTS(s) A[s] = A[s] + Y[s];
+            }
+        }
+        inverse_class(A, p.out + (size_t)by * img, p.tw);
     }
 #undef RL_FOR_LIVE_SLOTS
 }

@@ -147,7 +147,8 @@ struct OuterCol {
     static constexpr bool value = false;
     using Core = typename CfgFor<64>::Cfg;   // unused
     static constexpr int M = 2, C = 8, MIN_WAVES = 1;
-    static constexpr bool MULTI = false;
+    static constexpr int FOUR_WAVES = 0;                 // colconv_outer4_body: 1 its multi-view modes, 2 the per-image mode too
+    static constexpr int MULTI_MODES = 0;                // KernelTable::col_multi bits the plan should use
 };
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
@@ -160,21 +161,27 @@ struct OuterCol {
 #ifndef RL_OUTER_MIN_WAVES
 #define RL_OUTER_MIN_WAVES 4
 #endif
-// The multi-view column modes on the outer-decimation body (COL_H_MULTI: one forward transform, V products and inverse
-// transforms; COL_HT_SUM: V forward transforms summed before one inverse) hold two 4 x 10 register sets: 256 VGPRs + 81 spilled
-// dwords, one workgroup per CU.  Measured at 2048^2, 4 views, per 4-frame launch: H 0.355 -> 0.478 ms, H_t 0.354 -> 0.525 ms,
-// ROW_UPDATE 0.193 -> 0.069 ms (one spectrum instead of four); bench.py --size 2048: 186-189 -> 172 frames/s.  The 37 % of
-// column traffic they save does not pay for the halved occupancy: OFF (the per-image kernel runs V times per frame); the
-// host emulation keeps testing the modes (test_outer_decimation_multi_view_modes).
-#ifndef RL_OUTER_MULTI
-#define RL_OUTER_MULTI 0
+// The multi-view column modes of the long transforms live in colconv_outer4_body (four waves per column, one register set per
+// wave).  History: on colconv_outer_body they hold two 4 x 10 register sets (256 VGPRs + 81 spilled dwords, one workgroup per CU:
+// round 2, H 0.355 -> 0.478 ms per 4-frame launch); on a two-waves-per-column body (round 3) 128 VGPRs + 60-100 spilled dwords,
+// 991 us against 730 us for the V per-image launches.  Both removed.
+#ifndef RL_OUTER_FOUR_WAVES
+#define RL_OUTER_FOUR_WAVES 1      // 1: colconv_outer4_body for the multi-view modes; 2: for the per-image mode too (measured 40 % slower)
+#endif
+#ifndef RL_OUTER_H_MULTI
+#define RL_OUTER_H_MULTI 0
 #endif
 template <>
 struct OuterCol<2304> {
     static constexpr bool value = RL_OUTER_2304 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
-    static constexpr bool MULTI = RL_OUTER_MULTI != 0;   // COL_H_MULTI / COL_HT_SUM kernels (two M x 10 register sets)
+    static constexpr int FOUR_WAVES = RL_OUTER_FOUR_WAVES;
+    // Measured at 2048^2, 4 views, 6-frame launches (us, in situ): H as 24 per-image launches of colconv_outer_body 730, as
+    // COL_H_MULTI on four waves 952; H_t per image 730 + ROW_UPDATE over 4 spectra 732, as COL_HT_SUM on four waves 974 +
+    // ROW_UPDATE over one spectrum 179.  So the plan uses the Fourier-domain view sum (bit 1 of KernelTable::col_multi), not the
+    // shared forward transform (bit 0: RL_OUTER_H_MULTI).
+    static constexpr int MULTI_MODES = FOUR_WAVES ? (2 | (RL_OUTER_H_MULTI ? 1 : 0)) : 0;
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
@@ -187,7 +194,7 @@ struct OuterCol<4608> {
     static constexpr bool value = RL_OUTER_4608 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 8, C = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
-    static constexpr bool MULTI = false;                 // (two 8 x 10 register sets do not fit)
+    static constexpr int FOUR_WAVES = 0, MULTI_MODES = 0;
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

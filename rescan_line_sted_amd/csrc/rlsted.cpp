@@ -333,7 +333,10 @@ struct rl_deconv {
     size_t n_img() const { return (size_t)ny * nx; }
     size_t n_spec() const { return spec_image_elems(ny, pitch); }   // complex elements of one spectrum image
 
-    bool wave_private_y() const { return ty->col_multi[dtype] != 0; }    // the multi-view column modes exist
+    bool col_multi = true;   // RLSTED_COL_MULTI=0 (A/B knob): V per-image column launches even where the multi-view modes exist
+    // KernelTable::col_multi: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM.  wave_private_y(): the Fourier-domain view sum exists (and is wanted)
+    bool wave_private_y() const { return col_multi && (ty->col_multi[dtype] & 2) != 0; }
+    bool h_multi() const { return col_multi && (ty->col_multi[dtype] & 1) != 0; }
     bool psf_transposed() const { return ty->psf_transposed[dtype] != 0; }   // psf_hat is [view][Kx][Ly]
     template <typename T>
     int col_t(const void* in, void* out, int frames, ColKind kind) {
@@ -349,8 +352,11 @@ struct rl_deconv {
         p.mode = COL_PER_IMAGE;
         p.in_sb = kind == COL_H ? 1 : V;
         p.in_sv = kind == COL_H ? 0 : 1;
-        if (V > 1 && wave_private_y() && kind != COL_HT_VIEW) {
-            p.mode = kind == COL_H ? COL_H_MULTI : COL_HT_SUM;
+        if (V > 1 && kind == COL_H && h_multi()) {
+            p.mode = COL_H_MULTI;
+            gy = (unsigned)frames;
+        } else if (V > 1 && kind == COL_HT_FUSED && wave_private_y()) {
+            p.mode = COL_HT_SUM;
             gy = (unsigned)frames;
         } else if (kind == COL_HT_FUSED && V > 1) {
             return fail(RL_ERR_STATE, "internal: fused H_t needs a wave-private column transform");
@@ -956,7 +962,7 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
     // ---- strategy selection: direct separable stencils when every view is rank 1 and small ----
     const int sep_mode = getenv("RLSTED_SEP") ? atoi(getenv("RLSTED_SEP")) : 1;
     const int max_taps = getenv("RLSTED_SEP_MAX_TAPS") ? atoi(getenv("RLSTED_SEP_MAX_TAPS")) : 16;
-    if (sep_mode > 0 && (sep_mode > 1 || h->py + h->px <= max_taps) && h->py <= 4096 && h->px <= 4096) {
+    if (sep_mode > 0 && (sep_mode > 1 || h->py + h->px <= max_taps) && sep_two_pass_fits(h->dtype, h->py, h->px)) {
         const size_t py = h->py, px = h->px;
         std::vector<double> u(V * py), vv(V * px);
         bool rank1 = true;
@@ -1099,6 +1105,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
         if (h->lanes < 1) h->lanes = 1;
         if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
     }
+    if (getenv("RLSTED_COL_MULTI")) h->col_multi = atoi(getenv("RLSTED_COL_MULTI")) != 0;
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     h->exact_norm = getenv("RLSTED_EXACT_NORM") ? atoi(getenv("RLSTED_EXACT_NORM")) != 0 : (dtype == RL_F32);
     {   // ratio - 1 needs H_t(ones) == the normaliser: every PSF value >= 0 (and not the 16-bit storage study, whose scales assume ratio spectra)

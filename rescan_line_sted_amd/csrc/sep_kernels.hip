@@ -246,6 +246,8 @@ hipError_t sep2d_t(int mode, const void* in, const void* uf, const void* vf, con
     }
 }
 
+constexpr size_t kSepMaxLds = 160 * 1024;   // LDS of a gfx950 compute unit
+
 template <typename T>
 hipError_t rows_t(const void* in, void* out, const void* v, int images, int ny, int nx, int px, int V, int in_div, hipStream_t s) {
     const dim3 grid((unsigned)((nx + kRowSeg - 1) / kRowSeg), (unsigned)ny, (unsigned)images);
@@ -257,6 +259,17 @@ hipError_t cols_t(int mode, const void* tmp, const void* u, const void* aux, con
                   int ny, int nx, int py, int V, hipStream_t s) {
     const dim3 grid((unsigned)((nx + kColW - 1) / kColW), (unsigned)((ny + kColH - 1) / kColH), (unsigned)frames_or_images);
     const size_t lds = (size_t)(kColH + py - 1) * kColW * sizeof(T);
+    if (lds > kSepMaxLds) return hipErrorInvalidValue;   // (the plan does not choose the stencils for such a PSF: sep_cols_fits)
+    if (lds > 65536) {   // above the default dynamic-LDS limit: raise it, once per kernel
+        static const hipError_t raised = [] {
+            hipError_t e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_RATIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_SUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_UPDATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
+            return e;
+        }();
+        if (raised != hipSuccess) return raised;
+    }
     switch (mode) {
         case SEP_STORE: k_sep_cols<T, SEP_STORE><<<grid, 256, lds, s>>>((const T*)tmp, (const T*)u, (const T*)aux, (const T*)norm, (T*)dst, ny, nx, py, V); break;
         case SEP_RATIO: k_sep_cols<T, SEP_RATIO><<<grid, 256, lds, s>>>((const T*)tmp, (const T*)u, (const T*)aux, (const T*)norm, (T*)dst, ny, nx, py, V); break;
@@ -295,6 +308,11 @@ size_t sep2d_lds_bytes(int dtype, int py, int px, int V) {
     return sep_th32() == 64 ? sep2d_lds<float, 64>(py, px, V) : sep2d_lds<float, 32>(py, px, V);
 }
 bool sep2d_fits(int dtype, int py, int px, int V) { return sep2d_lds_bytes(dtype, py, px, V) <= kSep2dMaxLds; }
+// the two-pass form: the column pass stages (32 + py - 1) rows of 64 columns, the row pass 256 + px - 1 values
+bool sep_two_pass_fits(int dtype, int py, int px) {
+    const size_t es = dtype == DT_F32 ? 4 : 8;
+    return (size_t)(kColH + py - 1) * kColW * es <= kSepMaxLds && (size_t)(kRowSeg + px - 1) * es <= 65536;
+}
 hipError_t sep2d(int dtype, int mode, const void* in, const void* taps_uf, const void* taps_vf, const void* aux, const void* norm,
                  void* dst, int frames, int ny, int nx, int py, int px, int V, hipStream_t s) {
     if (frames < 1) return hipSuccess;

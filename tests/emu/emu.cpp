@@ -231,18 +231,53 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
     run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  cx<T>* l = reinterpret_cast<cx<T>*>(lds);
-                 if (mode == COL_H_MULTI) {
-                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_H_MULTI>(p, tid, bx, by, l, s);
-                     else colconv_outer_body<Core, M, C, T, false, COL_H_MULTI>(p, tid, bx, by, l, s);
-                 } else if (mode == COL_HT_SUM) {
-                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_HT_SUM>(p, tid, bx, by, l, s);
-                     else colconv_outer_body<Core, M, C, T, false, COL_HT_SUM>(p, tid, bx, by, l, s);
-                 } else {
-                     if (real_psf) colconv_outer_body<Core, M, C, T, true>(p, tid, bx, by, l, s);
-                     else colconv_outer_body<Core, M, C, T, false>(p, tid, bx, by, l, s);
-                 }
+                 if (real_psf) colconv_outer_body<Core, M, C, T, true>(p, tid, bx, by, l, s);
+                 else colconv_outer_body<Core, M, C, T, false>(p, tid, bx, by, l, s);
              });
     return 0;
+}
+// colconv_outer4_body: four waves per column (L = 4 * Li), C columns per workgroup
+template <class Core, int C, typename T, int WAVES = 4>
+static int col_outer4_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
+                        int in_sb, int in_sv, int mode) {
+    constexpr int M = 4, L = M * Core::L;
+    constexpr int n_core = PassTw<Core, false, 0>::TOTAL;
+    std::vector<double> h(2 * (size_t)(n_core + (M - 1) * Core::L));
+    fill_pass_twiddles<Core>(h.data());
+    for (int q = 1; q < M; ++q)
+        for (int k = 0; k < Core::L; ++k) {
+            const long double a = -6.283185307179586476925286766559005768L * (long double)q * (long double)k / (long double)L;
+            h[2 * (size_t)(n_core + (q - 1) * Core::L + k)] = (double)cosl(a);
+            h[2 * (size_t)(n_core + (q - 1) * Core::L + k) + 1] = (double)sinl(a);
+        }
+    std::vector<cx<T>> tw(h.size() / 2);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = mk<T>((T)h[2 * i], (T)h[2 * i + 1]);
+    ColParams<T> p;
+    p.in = reinterpret_cast<const cx<T>*>(in);
+    p.out = reinterpret_cast<cx<T>*>(out);
+    p.psf_hat = real_psf ? nullptr : reinterpret_cast<const cx<T>*>(psf_hat);
+    p.psf_hat_re = real_psf ? psf_hat : nullptr;
+    p.tw = tw.data();
+    p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
+    p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
+    if constexpr (WAVES == 4) {
+        run_grid((kx + C - 1) / C, p.images, 256 * C, (size_t)4 * C * LdsSlots<Core>::value * sizeof(cx<T>),
+                 [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                     cx<T>* l = reinterpret_cast<cx<T>*>(lds);
+                     if (mode == COL_H_MULTI) {
+                         if (real_psf) colconv_outer4_body<Core, C, T, true, COL_H_MULTI>(p, tid, bx, by, l, s);
+                         else colconv_outer4_body<Core, C, T, false, COL_H_MULTI>(p, tid, bx, by, l, s);
+                     } else if (mode == COL_HT_SUM) {
+                         if (real_psf) colconv_outer4_body<Core, C, T, true, COL_HT_SUM>(p, tid, bx, by, l, s);
+                         else colconv_outer4_body<Core, C, T, false, COL_HT_SUM>(p, tid, bx, by, l, s);
+                     } else {
+                         if (real_psf) colconv_outer4_body<Core, C, T, true>(p, tid, bx, by, l, s);
+                         else colconv_outer4_body<Core, C, T, false>(p, tid, bx, by, l, s);
+                     }
+                 });
+        return 0;
+    }
+    return -2;
 }
 template <int L, typename T>
 static int row_pair_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, int ny, int nx, int frames, int in_mod) {
@@ -293,15 +328,17 @@ int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double
     if (Li == 576 && M == 8) return col_outer_t<C576, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     return -2;
 }
-// the multi-view modes of the same body (M = 4): mode 1 = COL_H_MULTI (in [frames], out [frames*V]), 2 = COL_HT_SUM
-// (in [frames*V], out [frames])
-int emu_col_outer_multi_f64(int Li, int mode, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
-                            int pitch, int V, int frames) {
+// colconv_outer4_body (four waves per column, L = 4 * Li): mode 0 = COL_PER_IMAGE (in [frames] or [frames*V] by in_sb / in_sv,
+// out [frames*V]), 1 = COL_H_MULTI, 2 = COL_HT_SUM; C = columns per workgroup: 1, 2 (fast) or 4 (the device's 1024 threads)
+int emu_col_outer4_f64(int Li, int C, int mode, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
+                       int pitch, int V, int frames, int in_sb, int in_sv) {
     using C256 = CfgFor<256>::Cfg;
     using C576 = CfgFor<576>::Cfg;
-    if (mode != COL_H_MULTI && mode != COL_HT_SUM) return -2;
-    if (Li == 256) return col_outer_t<C256, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, 1, 0, mode);
-    if (Li == 576) return col_outer_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, 1, 0, mode);
+    if (mode != COL_PER_IMAGE && mode != COL_H_MULTI && mode != COL_HT_SUM) return -2;
+    if (Li == 256 && C == 1) return col_outer4_t<C256, 1, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
+    if (Li == 256 && C == 2) return col_outer4_t<C256, 2, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
+    if (Li == 576 && C == 1) return col_outer4_t<C576, 1, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
+    if (Li == 256 && C == 4) return col_outer4_t<C256, 4, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
     return -2;
 }
 

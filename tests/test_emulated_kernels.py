@@ -21,6 +21,8 @@ ROW_FWD, ROW_INV, ROW_RATIO, ROW_UPDATE, ROW_ADJ = range(5)
 
 @pytest.fixture(scope='module')
 def emu():
+    if os.environ.get('RLSTED_EMU_LIB'):      # tools/asan_emu.sh: the AddressSanitizer / UBSan build of the same source
+        return ctypes.CDLL(os.environ['RLSTED_EMU_LIB'])
     so = os.path.join(EMU_DIR, 'libemu.so')
     src = os.path.join(EMU_DIR, 'emu.cpp')
     deps = [src] + [os.path.join(ROOT, 'rescan_line_sted_amd', 'csrc', f)
@@ -374,30 +376,32 @@ def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
             assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
 
 
-@pytest.mark.parametrize('Li,mode,ny,kx,real_psf', [(256, 1, 901, 9, 0), (256, 2, 600, 3, 1), (576, 1, 2048, 2, 1), (576, 2, 2040, 2, 0)])
-def test_outer_decimation_multi_view_modes(emu, Li, mode, ny, kx, real_psf):
-    """The multi-view modes of colconv_outer_body (M = 4): COL_H_MULTI -- one forward transform feeds the V products
-    and inverse transforms -- and COL_HT_SUM -- the V products are summed before one inverse transform."""
-    M, V, frames = 4, 3, 2
-    L = M * Li
+@pytest.mark.parametrize('Li,C,mode,ny,kx,real_psf', [(256, 1, 0, 901, 2, 0), (256, 2, 0, 1024, 3, 1), (576, 1, 0, 2048, 2, 1),
+                                                      (256, 2, 1, 900, 2, 0), (256, 1, 2, 603, 2, 1), (576, 1, 1, 2040, 1, 1),
+                                                      (576, 1, 2, 2048, 1, 0), (256, 4, 0, 1000, 5, 0)])
+def test_outer_decimation_four_waves_per_column(emu, Li, C, mode, ny, kx, real_psf):
+    """colconv_outer4_body (round 3): L = 4 * Li with FOUR waves per column -- wave g transforms residue class g and owns
+    the spectrum quarter X[k + Li g]; the radix-4 step is an all-to-all among the column's waves through LDS.  All three
+    modes against numpy; ragged heights, partial column tiles, real and complex multipliers."""
+    L, V, frames = 4 * Li, 3, 2
     pitch = (kx + 7) // 8 * 8
-    rng = np.random.default_rng(Li + mode + ny)
-    n_in = frames if mode == 1 else frames * V
-    n_out = frames * V if mode == 1 else frames
+    rng = np.random.default_rng(Li + mode + ny + C)
+    n_in = frames if mode in (0, 1) else frames * V
+    n_out = frames if mode == 2 else frames * V
     x = np.zeros((n_in, ny, pitch), dtype=np.complex128)
     x[:, :, :kx] = rng.standard_normal((n_in, ny, kx)) + 1j * rng.standard_normal((n_in, ny, kx))
     ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
-    out = np.zeros((n_out, ny, pitch), dtype=np.complex128)
+    out = np.full((n_out, ny, pitch), np.nan + 0j, dtype=np.complex128)
     psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
-    rc = emu.emu_col_outer_multi_f64(Li, mode, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames)
+    rc = emu.emu_col_outer4_f64(Li, C, mode, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, 1, 0)
     assert rc == 0
     full = np.zeros((n_in, L, kx), dtype=np.complex128)
     full[:, :ny] = x[:, :, :kx]
     spec = np.fft.fft(full, axis=1)
     for f in range(frames):
-        if mode == 1:
+        if mode in (0, 1):
             for v in range(V):
-                ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L
+                ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L     # the kernels leave the 1/L to psf_hat's scale
                 assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
         else:
             ref = np.fft.ifft(sum(spec[f * V + v] * ph[v].T for v in range(V)), axis=0)[:ny] * L

@@ -160,3 +160,21 @@ def test_separable_random_small_cases_vs_oracle(lib, seed):
         for _ in range(3):
             d.iterate()
         assert max_rel(plan.estimate()[f], d.estimate[0]) < 1e-11, (ny, nx, py, px, V, B)
+
+
+@pytest.mark.parametrize('dtype,py,expect_sep', [('f64', 107, True), ('f32', 230, True), ('f64', 300, False)])
+def test_long_column_stencils_raise_their_lds_limit_or_fall_back(lib, dtype, py, expect_sep):
+    """the two-pass column stencil stages (32 + py - 1) x 64 values -- above the 64 KB default dynamic-LDS
+    limit from py = 98 (f64) / 226 (f32) on, e.g. the 107-tap figure-2 line PSFs under RLSTED_SEP=2.  The kernel's limit is
+    raised; where the tile would not fit the 160 KB of a compute unit the plan keeps the FFT strategy."""
+    u, v = gauss(py, py / 8.0), gauss(9, 1.5)
+    psf = [np.outer(u, v)[None] / np.outer(u, v).sum()]
+    rng = np.random.default_rng(py)
+    x = rng.random((2, 90, 70))
+    sep = plan_with(lib, 2, psf, 2, 90, 70, one_kernel=False, dtype=dtype)
+    assert sep.strategy()['separable'] == expect_sep
+    fft = plan_with(lib, 0, psf, 2, 90, 70, dtype=dtype)
+    assert not fft.strategy()['separable']
+    assert max_rel(sep.forward(x), fft.forward(x)) < (1e-12 if dtype == 'f64' else 2e-6)
+    d = orc.Deconvolver(psf)
+    assert max_rel(sep.forward(x)[0, 0], d.H(x[:1])[0][0]) < (1e-12 if dtype == 'f64' else 2e-6)
