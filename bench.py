@@ -294,12 +294,20 @@ def extra_leg(size, n_views, dtype, B, steps, warmup, device):
     es = 4 if dtype == 'f32' else 8
     alg = algorithmic_bytes_per_frame(size * size, len(psf), K_ITERS) * es // 4
     info = plan.info()
+    fabric = None       # fabric bytes / algorithmic bytes of one RL iteration at this launch shape, where the PMC passes were recorded
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic_%d.json' % size)))
+        if pmc.get('n_psf') == len(psf) and pmc.get('dtype') == dtype and pmc.get('shape') == [size, size]:
+            fabric = pmc.get('rl_iteration')
+    except (OSError, ValueError):
+        pass
     return {'metric': 'simulated frames/s (%dx%d, 20 RL iters)' % (size, size), 'value': value, 'unit': 'frames/s',
             'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3, 'dtype': dtype,
             'config': {'workload': name, 'frames_per_gpu_per_step': B, 'n_psf': len(psf), 'rl_iters': K_ITERS,
                        'fft': '%dx%d' % (info['ly'], info['lx']), 'frame_pairs': plan.strategy()['frame_pairs']},
             'whole_path': {'algorithmic_bytes_per_frame': alg, 'bytes_per_element': es, 'GBps': alg * value / 1e9,
-                           'frac': alg * value / 1e9 / HBM_PEAK_GBS}}
+                           'frac': alg * value / 1e9 / HBM_PEAK_GBS},
+            'rl_iteration_traffic': fabric}
 
 
 # ------------------------------------------------------------------ BASELINE config 4: the sharded figure-2 sweep
@@ -481,16 +489,16 @@ def main():
     alg_iter = 4 * n_pix * (3 * V + 4) * FL
     achieved = alg_iter / (iter_ms * 1e-3) / 1e9
     traffic, per_kernel_traffic, pmc_file = None, None, None
-    for rnd in ('r03', 'r02'):
+    for name in ('pmc_traffic.json', 'pmc_traffic_%d.json' % size):
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03', name)))
         except (OSError, ValueError):
             continue
         if (pmc.get('frames_per_launch') == FL and pmc.get('dtype') == args.dtype and pmc.get('n_psf') == V
                 and pmc.get('shape') == [size, size] and all(k in pmc for k in rl_kernels)):
             per_kernel_traffic = {k: pmc[k]['fabric_bytes_per_launch'] for k in rl_kernels}
             traffic = sum(per_kernel_traffic.values())
-            pmc_file = 'profiles/%s/pmc_traffic.json' % rnd
+            pmc_file = 'profiles/r03/' + name
             break
     alg_frame = algorithmic_bytes_per_frame(n_pix, V, K_ITERS)
     # The batch slices run on two streams: on average `concurrency` kernels are in flight, each with its

@@ -115,6 +115,22 @@ template <>
 struct LdsGather<576> {
     static constexpr bool value = RL_LDS_GATHER != 0;
 };
+// the long, workgroup-synchronous lengths (row kernels; f64 column kernels): RL_LDS_GATHER_LONG
+#ifndef RL_LDS_GATHER_LONG
+#define RL_LDS_GATHER_LONG 1   // measured on the row kernels alone: 2048^2 -2 ... -3 %, 4096^2 ROW_RATIO -16 %, ROW_UPDATE -4 %
+#endif
+template <>
+struct LdsGather<1152> {
+    static constexpr bool value = RL_LDS_GATHER_LONG != 0;
+};
+template <>
+struct LdsGather<2304> {
+    static constexpr bool value = RL_LDS_GATHER_LONG != 0;
+};
+template <>
+struct LdsGather<4608> {
+    static constexpr bool value = RL_LDS_GATHER_LONG != 0;
+};
 
 // Geometry of the COLUMN kernels where it differs from the row kernels' (same length, its own radix
 // list, thread count and twiddle table).  A column workgroup holds C whole columns in LDS, so few

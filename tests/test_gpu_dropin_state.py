@@ -167,3 +167,29 @@ def test_random_method_sequences_match_the_reference_class(st, seed, tmp_path):
             o.num_iterations = 0
         if d.num_iterations > 0:
             assert max_rel(d.estimate, o.estimate) < 1e-10, log
+
+
+def test_views_of_different_psf_shapes(st, tmp_path):
+    """The reference convolves every view with its own PSF, whatever its shape (ref:573-576, 584-588: fftconvolve per view).
+    The device plan has one (py, px) for all views: smaller PSFs are zero-embedded around their centre tap
+    (line_sted_tools._common_shape), which changes nothing -- H, H_t, the normaliser and the iterations equal the oracle's
+    per-view convolutions, for odd / even / 1-row shapes whose centres (p - 1) // 2 differ."""
+    rng = np.random.default_rng(12)
+    psfs = [rng.random((1, 9, 11)) + 0.01, rng.random((1, 6, 4)) + 0.01, rng.random((1, 1, 7)) + 0.01, rng.random((1, 8, 3)) + 0.01]
+    x = rng.random((2, 40, 52)) * 30
+    d = st.Deconvolver(psfs, str(tmp_path) + '/', verbose=False)
+    o = orc.Deconvolver(psfs)
+    assert [p.shape for p in d.psfs] == [p.shape for p in psfs]          # the public attribute keeps the caller's arrays
+    for a, b in zip(d.H(x), o.H(x)):
+        assert max_rel(a, b) < 1e-12
+    y = [rng.random(x.shape) for _ in psfs]
+    assert max_rel(d.H_t(y, normalize=False), o.H_t(y, normalize=False)) < 1e-12
+    assert max_rel(d.H_t(y), o.H_t(y)) < 1e-12
+    d.create_data_from_object(x, 1e7, random_seed=4)
+    o.create_data_from_object(x, 1e7, noisy_measurement=d.noisy_measurement)
+    for _ in range(6):
+        d.iterate()
+        o.iterate()
+    assert max_rel(d.estimate, o.estimate) < 1e-10
+    with pytest.raises(NotImplementedError):                              # PSFs with depth couple the z slices: not on the device
+        st.Deconvolver([rng.random((3, 5, 5))], str(tmp_path) + '/', verbose=False)

@@ -5,7 +5,7 @@
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- \
         python bench.py --steps 1 --warmup 0 --no-cpu-baseline --kernel-reps 2
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- (same)
-    python tools/pmc_traffic.py <fetch counter csv> <write counter csv> <out json> [batch]
+    python tools/pmc_traffic.py <fetch counter csv> <write counter csv> <out json> [frames per launch] [size] [views]
 
 Only the most frequent launch shape of each kernel is kept: for the four RL kernels that is
 the slice of the batch the RL loop launches them on (bench.py: roofline.frames_per_launch, pass it
@@ -23,9 +23,10 @@ NAMES = (  # (regex on the kernel name, key in the json); first match wins
     (r'k_rowpair<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpair<\d+, \d+, 3,', 'rowpass_UPDATE'), (r'k_rowpair<\d+, \d+, 0,', 'rowpair_FWD'),
     (r'k_rowpass<\d+, \d+, 0,', 'rowpass_FWD'), (r'k_rowpass<\d+, \d+, 1,', 'rowpass_INV'),
     (r'k_rowpass<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpass<\d+, \d+, 3,', 'rowpass_UPDATE'),
-    (r'k_rowpass<\d+, \d+, 4,', 'rowpass_ADJ'), (r'k_rowstream<\d+, \d+, 2,', 'rowstream_RATIO'),
-    (r'k_rowstream<\d+, \d+, 3,', 'rowstream_UPDATE'), (r'k_colstream<', 'colstream'),
-    (r'k_colconv<', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'))
+    (r'k_rowpass<\d+, \d+, 4,', 'rowpass_ADJ'),
+    (r'k_colconv_outer4<\d+, \d+, \w+, 2>', 'colconv_Ht'), (r'k_colconv_outer4<\d+, \d+, \w+, 1>', 'colconv_H'),
+    (r'k_colconv<\d+, \d+, 2,', 'colconv_Ht'), (r'k_colconv<\d+, \d+, 1,', 'colconv_H'),
+    (r'k_colconv', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'))
 
 
 def per_kernel(path, counter):
@@ -49,23 +50,28 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
-    fl = int(sys.argv[4]) if len(sys.argv) > 4 else 64
-    batch = 256
+    fl = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    size = int(sys.argv[5]) if len(sys.argv) > 5 else 512
+    views = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     res = {'_how': __doc__.strip().split('\n\n')[0] + ' (tools/pmc_traffic.py; FETCH_SIZE doubled, KB = 1024 B)',
-           'batch': batch, 'frames_per_launch': fl, 'dtype': 'f32', 'shape': [512, 512], 'n_psf': 1}
+           'frames_per_launch': fl, 'dtype': 'f32', 'shape': [size, size], 'n_psf': views}
     for key in sorted(set(fetch) | set(write)):
         f, w = fetch.get(key, 0.0), write.get(key, 0.0)
         # FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: Infinity Cache hits are counted too, so
         # this is fabric traffic (what leaves the XCD's L2), not bytes that reached HBM
         res[key] = {'fabric_bytes_per_launch': 2 * f * 1024 + w * 1024, 'fetch_kb_reported': f, 'write_kb_reported': w}
-    if 'colconv' in res:   # the H and H_t column passes are the same kernel
-        res['colconv_H'] = res['colconv_Ht'] = res['colconv']
-    if 'rowpass_FWD' in res:
-        # rowpass_FWD's most frequent shape is the slice too (est = 1 -> spectrum, H(obj) per slice)
-        res['_calibration'] = {'rowpass_FWD_must_read_bytes': fl * 512 * 512 * 4,
-                               'rowpass_FWD_fetch_reported_bytes': res['rowpass_FWD']['fetch_kb_reported'] * 1024}
+    if 'colconv' in res:   # the H and H_t column passes are the same kernel (single view / per-image launches)
+        for k in ('colconv_H', 'colconv_Ht'):
+            res.setdefault(k, res['colconv'])
+    rl = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE')
+    if all(k in res for k in rl):
+        total = sum(res[k]['fabric_bytes_per_launch'] for k in rl)
+        alg = 4 * size * size * (3 * views + 4) * fl
+        res['rl_iteration'] = {'fabric_bytes': total, 'algorithmic_bytes': alg, 'ratio': total / alg,
+                               'fabric_MB_per_frame_iteration': total / fl / 1e6}
     json.dump(res, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps({k: v['fabric_bytes_per_launch'] for k, v in res.items() if isinstance(v, dict) and 'fabric_bytes_per_launch' in v}))
+    print(json.dumps(res.get('rl_iteration')))
 
 
 if __name__ == '__main__':
