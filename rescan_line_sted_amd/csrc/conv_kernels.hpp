@@ -535,8 +535,10 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
 // the column's four waves through LDS (each writes its 9 values per lane, reads the three others':  (-i)^(q g) are
 // sign flips and swaps).  Per wave ONE register set (9 complex values per lane) -- so COL_H_MULTI / COL_HT_SUM hold
 // their persistent quarter beside the working set (colconv_outer_body's multi-view modes needed two 4 x 10 sets per lane:
-// 256 registers + spills; a two-waves-per-column form, built and measured in round 3, still spilled 60-100 registers and
-// lost to V per-image launches: both removed) -- and per image ONE load phase and ONE store phase over whole tile rows
+// 256 registers + spills; a two-waves-per-column form, built and measured in round 3, still spilled 60-100 registers in the
+// multi-view modes and lost to V per-image launches; its per-image mode, generalised to M = 8 with four classes per wave
+// (16 waves per CU at 4608 instead of 8) and with the next round's rows prefetched, ran 20-30 % SLOWER than colconv_outer_body
+// at both lengths -- 2048^2 530 against 684 frames/s, 4096^2 K = 100 19.4 against 28.2: all removed) -- and per image ONE load phase and ONE store phase over whole tile rows
 // and 6 workgroup barriers (16 in colconv_outer_body).  Workgroup = 4 C waves (C = 4 columns: 1024 threads, 32-byte row
 // segments, one workgroup per CU), LDS = 4 C core regions.  Measured at 2048^2 (fft_configs.hpp OuterCol<2304>): the
 // per-image mode is 40 % SLOWER than colconv_outer_body (one workgroup per CU: its load, transform and store phases do not

@@ -187,6 +187,7 @@ struct OuterCol {
 #ifndef RL_OUTER_H_MULTI
 #define RL_OUTER_H_MULTI 0
 #endif
+
 template <>
 struct OuterCol<2304> {
     static constexpr bool value = RL_OUTER_2304 != 0;

@@ -34,30 +34,6 @@ def _np_tif():
     return np_tif
 
 
-def _common_shape(psfs):
-    """The device plan holds one (py, px) for all views; the reference convolves each view with its own PSF, whatever
-    its shape (ref:573-576, 584-588).  A smaller PSF is embedded in zeros so that its centre tap -- index (p - 1) // 2 on each
-    axis, the 'same' convention of scipy.signal.fftconvolve -- lands on the centre of the common shape: zero taps add
-    nothing, so H / H_t are unchanged.  Common side = 2 max(taps below the centre, taps above it) + 1 per axis."""
-    shapes = {np.shape(p) for p in psfs}
-    if len(shapes) == 1:
-        return list(psfs)
-    side = []
-    for ax in (1, 2):
-        lo = max((np.shape(p)[ax] - 1) // 2 for p in psfs)
-        hi = max(np.shape(p)[ax] - 1 - (np.shape(p)[ax] - 1) // 2 for p in psfs)
-        side.append(2 * max(lo, hi) + 1)
-    out = []
-    for p in psfs:
-        p = np.asarray(p, dtype=np.float64)
-        big = np.zeros((1, side[0], side[1]))
-        oy = (side[0] - 1) // 2 - (p.shape[1] - 1) // 2
-        ox = (side[1] - 1) // 2 - (p.shape[2] - 1) // 2
-        big[0, oy:oy + p.shape[1], ox:ox + p.shape[2]] = p[0]
-        out.append(big)
-    return out
-
-
 class Deconvolver:
     """ref:478-594.  One PSF list ("views"), measurements as Python lists of
     (nz, ny, nx) float64 arrays, estimate updated in place by iterate()."""
@@ -87,7 +63,6 @@ class Deconvolver:
                 # Every PSF the reference's scripts build is (1, n, n); INTEGRATION.md section 4.
                 raise NotImplementedError(
                     'device path supports 2-D PSFs of shape (1, py, px); got %s' % (np.shape(p),))
-        self._device_psfs = _common_shape(self.psfs)    # views of different (py, px): zero-embedded around their centres
         self._plan = None
         self._aux_plans = {}            # H / H_t on shapes other than the data's (the RL state stays untouched)
         self._estimate = None
@@ -103,7 +78,7 @@ class Deconvolver:
         if p is None or (p.B, p.ny, p.nx) != (nz, ny, nx):
             if p is not None and self._estimate_stale:      # keep what the old plan computed
                 self._estimate, self._estimate_stale = p.estimate(), False
-            self._plan = DeconvPlan(self._device_psfs, nz, ny, nx, dtype=self.dtype, device=self.device)
+            self._plan = DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)
             self._measurement_on_device = False             # the host copy is pushed again when needed
             self._estimate_push = self._estimate is not None and np.shape(self._estimate) == (nz, ny, nx)
             if hasattr(self, 'H_t_normalization'):
@@ -121,7 +96,7 @@ class Deconvolver:
             return p
         key = (nz, ny, nx)
         if key not in self._aux_plans:
-            self._aux_plans = {key: DeconvPlan(self._device_psfs, nz, ny, nx, dtype=self.dtype, device=self.device)}
+            self._aux_plans = {key: DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)}
         return self._aux_plans[key]
 
     # ---- data ---------------------------------------------------------------

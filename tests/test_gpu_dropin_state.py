@@ -172,7 +172,7 @@ def test_random_method_sequences_match_the_reference_class(st, seed, tmp_path):
 def test_views_of_different_psf_shapes(st, tmp_path):
     """The reference convolves every view with its own PSF, whatever its shape (ref:573-576, 584-588: fftconvolve per view).
     The device plan has one (py, px) for all views: smaller PSFs are zero-embedded around their centre tap
-    (line_sted_tools._common_shape), which changes nothing -- H, H_t, the normaliser and the iterations equal the oracle's
+    (_lib.common_psf_shape, every DeconvPlan), which changes nothing -- H, H_t, the normaliser and the iterations equal the oracle's
     per-view convolutions, for odd / even / 1-row shapes whose centres (p - 1) // 2 differ."""
     rng = np.random.default_rng(12)
     psfs = [rng.random((1, 9, 11)) + 0.01, rng.random((1, 6, 4)) + 0.01, rng.random((1, 1, 7)) + 0.01, rng.random((1, 8, 3)) + 0.01]

@@ -129,22 +129,26 @@ def test_deconvolver_surface_matches_reference(tmp_path):
 
 
 def test_pmc_traffic_json_is_what_the_tool_makes_of_the_committed_counter_files(tmp_path):
-    """profiles/r02/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from
-    the committed rocprofv3 counter files with tools/pmc_traffic.py."""
+    """profiles/r03/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from the committed rocprofv3
+    counter files with tools/pmc_traffic.py; its per-iteration sum is what DESIGN.md quotes (12.9 MB per frame-iteration,
+    1.76x the algorithmic bytes)."""
     import json
     import subprocess
     import sys
-    prof = os.path.join(ROOT, 'profiles', 'r02')
+    prof = os.path.join(ROOT, 'profiles', 'r03')
     committed = json.load(open(os.path.join(prof, 'pmc_traffic.json')))
     out = tmp_path / 'traffic.json'
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'),
                            os.path.join(prof, 'pmc_fetch_size.csv'), os.path.join(prof, 'pmc_write_size.csv'),
-                           str(out), str(committed['frames_per_launch'])], stdout=subprocess.DEVNULL)
+                           str(out), str(committed['frames_per_launch']), '512', '1'], stdout=subprocess.DEVNULL)
     again = json.load(open(out))
     assert again == committed
-    # the doubled FETCH_SIZE reproduces the bytes rowpass_FWD must read to within 1 %
-    cal = committed['_calibration']
-    assert abs(2 * cal['rowpass_FWD_fetch_reported_bytes'] / cal['rowpass_FWD_must_read_bytes'] - 1) < 0.01
+    it = committed['rl_iteration']
+    assert it['algorithmic_bytes'] == 4 * 512 * 512 * 7 * committed['frames_per_launch']
+    assert 1.5 < it['ratio'] < 2.0
+    # the doubled FETCH_SIZE reproduces the bytes rowpass_FWD must read (32 frames x 512 x 512 x 4 bytes) to within 2 %
+    fwd = committed['rowpass_FWD']
+    assert abs(2 * fwd['fetch_kb_reported'] * 1024 / (committed['frames_per_launch'] * 512 * 512 * 4) - 1) < 0.02
 
 
 def test_psfs_of_different_shapes_are_embedded_on_a_common_centre():

@@ -24,5 +24,6 @@ cp "$(f stats2048 kernel_stats.csv)" $OUT/bench_2048_kernel_stats.csv
 # the raw counter CSVs are large: keep the per-kernel averages only
 python3 tools/pmc_summary.py "$(f pmc512_FETCH_SIZE counter_collection.csv)" "$(f pmc512_WRITE_SIZE counter_collection.csv)" > $OUT/summary_pmc512.txt
 python3 tools/pmc_summary.py "$(f pmc2048_FETCH_SIZE counter_collection.csv)" "$(f pmc2048_WRITE_SIZE counter_collection.csv)" > $OUT/summary_pmc2048.txt
+cp "$(f pmc512_FETCH_SIZE counter_collection.csv)" $OUT/pmc_fetch_size.csv; cp "$(f pmc512_WRITE_SIZE counter_collection.csv)" $OUT/pmc_write_size.csv
 rm -rf $OUT/pmc512_* $OUT/pmc2048_F* $OUT/pmc2048_W* $OUT/stats512 $OUT/stats2048 2>/dev/null || true
 ls -la $OUT
