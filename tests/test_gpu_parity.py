@@ -505,3 +505,26 @@ def test_frame_pair_loop_f32_within_contract(lib, golden, astronaut512, monkeypa
     print('pairs / per frame:', err)
     assert max(err['1'] + err['0']) < 3e-6, err                         # measured 0.7 ... 0.9e-6 (round 2: 0.75 ... 1.0e-5)
     assert np.mean(err['1']) < 1.25 * np.mean(err['0']), err
+
+
+def test_f32_plan_with_negative_psf_values_keeps_the_plain_iteration(lib):
+    """`ratio - 1` (conv_kernels.hpp rl_ratio) needs H_t(ones) == the normaliser, i.e. PSF values >= 0; a PSF with negative
+    lobes makes the plan fall back to the plain arithmetic (ref:527-530 literally), with the exact normaliser still
+    clamped per view (ref:587).  Both against the oracle, two views, f32."""
+    rng = np.random.default_rng(31)
+    pos = [rng.random((1, 9, 11)) + 0.05, rng.random((1, 9, 11)) + 0.05]
+    neg = [p.copy() for p in pos]
+    neg[1][0, 0, :3] = -0.02                                  # a small negative lobe at the edge of one view
+    x = rng.random((2, 60, 75)) * 50 + 5
+    for psfs in (pos, neg):
+        d = orc.Deconvolver(psfs)
+        d.create_data_from_object(x, 1e8, random_seed=2)
+        plan = lib.DeconvPlan(psfs, 2, 60, 75, dtype='f32')
+        plan.set_object(x, [1e8 * x[0].sum() / x.sum(), 1e8 * x[1].sum() / x.sum()])
+        plan.set_measurement(np.stack(d.noisy_measurement, axis=1))
+        d.H_t(d.noisy_measurement)                              # creates the oracle's normaliser (ref:589-592)
+        assert max_rel(plan.normalization(), d.H_t_normalization) < 1e-6
+        for _ in range(10):
+            d.iterate()
+        plan.iterate(10)
+        assert max_rel(plan.estimate(), d.estimate) < 5e-6
