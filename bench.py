@@ -405,6 +405,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('RLSTED_DEVICE', str(local_rank))     # PSF generation (psf.py) runs on this rank's own GPU too
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
     stub = os.environ.get('RLSTED_BENCH_STUB') == '1'
