@@ -501,40 +501,37 @@ RL_HD void fft_sync(Sync& sync) {
 // ---------------------------------------------------------------------------
 RL_HD int bitrev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
 
-// The three exchange stages as "o + s x" with a per-lane sign s = +-1 (one FMA per component: the product is exact, so this
-// IS the add or the subtract) and the stage twiddle as a per-lane complex factor w -- (1, 0) where the butterfly has none --
-// instead of computing sum, difference and every twiddled variant and selecting among them: 13 vector instructions per
-// element and direction instead of ~35 (round 3; the tail is 1/9 of the data and was 17 % of the kernels' VALU work).
-// The lane constants depend on the lane alone: the compiler hoists them out of the kernel's loops.
+// x *= exp(-+ 2 pi i m / 8), m = 0..3 (runtime, per lane)
+template <bool INV, typename T>
+RL_HD cx<T> mul_w8(cx<T> x, int m) {
+    const T h = (T)0.70710678118654752440084436210485;
+    cx<T> d = mk<T>(h * (x.re + (INV ? -x.im : x.im)), h * (x.im - (INV ? -x.re : x.re)));   // m = 1
+    cx<T> q = rot90<INV>(x);                                                                 // m = 2
+    cx<T> e = mk<T>(h * (q.re + (INV ? -q.im : q.im)), h * (q.im - (INV ? -q.re : q.re)));   // m = 3
+    return m == 0 ? x : (m == 1 ? d : (m == 2 ? q : e));
+}
+
 template <bool INV, bool DIT, typename T, class Sync>
 RL_HD cx<T> tail_dft8(cx<T> x, int lane, Sync& sync) {
     const int p = lane >> 3;
     const bool b2 = (p & 4) != 0, b1 = (p & 2) != 0, b0 = (p & 1) != 0;
-    const T s2 = b2 ? (T)-1 : (T)1, s1 = b1 ? (T)-1 : (T)1, s0 = b0 ? (T)-1 : (T)1;
-    // w = exp(-+ 2 pi i m / 8), m = p & 3, on the lanes whose stage-32 butterfly carries a twiddle (b2); 1 elsewhere
-    const T h = (T)0.70710678118654752440084436210485;
-    const int m = b2 ? (p & 3) : 0;
-    const T wre = m == 0 ? (T)1 : (m == 1 ? h : (m == 2 ? (T)0 : -h));
-    const T wfw = m == 0 ? (T)0 : (m == 2 ? (T)-1 : -h);              // imaginary part, forward sign
-    const cx<T> w = mk<T>(wre, INV ? -wfw : wfw);
-    const bool quarter = b1 && b0;                                     // the stage-16 butterfly's twiddle: -+i
     cx<T> o;
     if constexpr (!DIT) {
         o = mk<T>(sync.template shfl_xor<32>(x.re), sync.template shfl_xor<32>(x.im));
-        x = cmul(mk<T>(o.re + s2 * x.re, o.im + s2 * x.im), w);
+        x = b2 ? mul_w8<INV>(o - x, p & 3) : x + o;
         o = mk<T>(sync.template shfl_xor<16>(x.re), sync.template shfl_xor<16>(x.im));
-        x = mk<T>(o.re + s1 * x.re, o.im + s1 * x.im);
-        if (quarter) x = rot90<INV>(x);
+        x = b1 ? (b0 ? rot90<INV>(o - x) : o - x) : x + o;
         o = mk<T>(sync.template shfl_xor<8>(x.re), sync.template shfl_xor<8>(x.im));
-        x = mk<T>(o.re + s0 * x.re, o.im + s0 * x.im);
+        x = b0 ? o - x : x + o;
     } else {
         o = mk<T>(sync.template shfl_xor<8>(x.re), sync.template shfl_xor<8>(x.im));
-        x = mk<T>(o.re + s0 * x.re, o.im + s0 * x.im);
-        if (quarter) x = rot90<INV>(x);
+        x = b0 ? o - x : x + o;
+        if (b1 && b0) x = rot90<INV>(x);
         o = mk<T>(sync.template shfl_xor<16>(x.re), sync.template shfl_xor<16>(x.im));
-        x = cmul(mk<T>(o.re + s1 * x.re, o.im + s1 * x.im), w);
+        x = b1 ? o - x : x + o;
+        if (b2) x = mul_w8<INV>(x, p & 3);
         o = mk<T>(sync.template shfl_xor<32>(x.re), sync.template shfl_xor<32>(x.im));
-        x = mk<T>(o.re + s2 * x.re, o.im + s2 * x.im);
+        x = b2 ? o - x : x + o;
     }
     return x;
 }
