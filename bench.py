@@ -508,6 +508,9 @@ def main():
     concurrency = max(1.0, busy_ms / max(dev_ms / args.steps, 1e-9))
     roofline = {
         'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+        'note': 'priced against the HBM roofline as BASELINE.json asks; the SQ counters (profiles/r03/sq_counters_512.txt) show the '
+                'three RL kernels 80-90 % VALU-active when they run alone: fp32 vector issue, not memory, is what the path waits for '
+                '(DESIGN.md section 4)',
         'kernel': 'one RL iteration over one slice = 4 launches: k_colconv, k_rowpair<RATIO>, k_colconv, k_rowpair<UPDATE>',
         'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
         'algorithmic_bytes': alg_iter, 'traffic': traffic, 'traffic_over_algorithmic': traffic / alg_iter if traffic else None,
