@@ -351,3 +351,17 @@ def test_psf_report_output_dir_writes_the_reference_file_set(st, golden, tmp_pat
     out = str(tmp_path / 'point')
     st.generate_psfs((1, 27, 27), 0.25, 9.0, 3.4, psf_type='point', output_dir=out, verbose=False)
     assert len(os.listdir(out)) == 5
+
+
+def test_line_extras_argument_errors_are_reported():
+    """rl_psf_generate_line_extras: a rescan ratio < 1 (the caller must pass the ratio a previous generate reported: it sizes
+    the second buffer) and a NULL context are errors, not crashes; NULL output pointers are allowed."""
+    import ctypes
+    from rescan_line_sted_amd import _lib, psf
+    ctx = psf._ctx()
+    rc = _lib.lib.rl_psf_generate_line_extras(ctx.handle, 27, 27, 0.25, 9.0, 3.4, 0, None, None)
+    assert rc != 0 and b'rescan_ratio' in _lib.lib.rl_last_error()
+    assert _lib.lib.rl_psf_generate_line_extras(None, 27, 27, 0.25, 9.0, 3.4, 3, None, None) != 0
+    em = np.empty((27, 27))
+    _lib.check(_lib.lib.rl_psf_generate_line_extras(ctx.handle, 27, 27, 0.25, 9.0, 3.4, 3, _lib.ptr(em), None))
+    assert em.sum() == pytest.approx(1.0, rel=1e-12) and em.argmax() == 13 * 27 + 13      # a normalised Gaussian centred on the array
