@@ -91,6 +91,16 @@ RL_HD cx<T> rl_spec_round(cx<T> v, float qscale) {
 // pair -- was built and measured in round 1: the column kernel's fabric reads did not change, 1.1 % slower; removed.)
 RL_HD size_t spec_image_elems(int ny, int pitch) { return (size_t)ny * pitch; }
 RL_HD size_t spec_off(int row, int col, int pitch) { return (size_t)row * pitch + col; }
+// The 4 x 4 blocked layout of the ratio spectra that feed colconv_outer4_body's COL_HT_SUM (round 3): element (row, col) at
+//     ((row / 4) * (pitch / 4) + col / 4) * 16 + (row % 4) * 4 + col % 4
+// -- 4 rows x 4 columns = one 128-byte line (f32).  That body reads 4-column tiles, residue class row % 4 = g by wave group g:
+// in row-major order every 32-byte piece it needs sits in a line of its own row and 3/4 of each fetched line is thrown away
+// (PMC: 465 MB of fabric traffic per 2048^2 frame against 137 MB of spectra and multipliers); blocked, the four wave groups of
+// ONE workgroup read the four pieces of the same line.  The image then holds (ny rounded up to 4) rows.
+RL_HD int spec_rows4(int ny) { return (ny + 3) & ~3; }
+RL_HD size_t spec_off4(int row, int col, int pitch) {
+    return ((size_t)(row >> 2) * (pitch >> 2) + (col >> 2)) * 16 + ((row & 3) << 2) + (col & 3);
+}
 
 // ------------------------------ column pass --------------------------------
 // For one tile of C spectrum columns: forward FFT along y (rows >= ny are
@@ -111,6 +121,7 @@ struct ColParams {
     // psf_hat ([view][kx][L]); used by the REALP instantiations of the wave-private column kernel
     // (half the multiplier bytes, a real x complex product).  nullptr: the complex multiplier.
     const T* psf_hat_re = nullptr;
+    int in_blocked4 = 0;    // colconv_outer4_body: the input images are in the 4 x 4 blocked layout (spec_off4)
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
@@ -563,7 +574,8 @@ RL_HD void colconv_outer4_body(const ColParams<T>& p, int tid, int bx, int by, c
     const int g = w / C, cw = w % C;                     // class / spectrum quarter, and column, of this wave
     const int col0 = bx * C, col = col0 + cw;
     const bool colok = col < p.kx;
-    const size_t img = spec_image_elems(p.ny, p.pitch);
+    const size_t img = spec_image_elems(p.ny, p.pitch);                                           // output images (row-major)
+    const size_t img_in = p.in_blocked4 ? spec_image_elems(spec_rows4(p.ny), p.pitch) : img;     // input images
     LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
     cx<T>* __restrict__ const mine = lds + w * LP;
     cx<T>* __restrict__ const group_lds = lds + g * C * LP;      // the regions of this class group: its tile
@@ -586,7 +598,8 @@ RL_HD void colconv_outer4_body(const ColParams<T>& p, int tid, int bx, int by, c
             const int e = th + it * NG;
             const int row = M * (e / C) + g, c = e % C;
             x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
+            if (row < p.ny && col0 + c < p.kx)
+                x[it] = rl_ldg(sync, in + (p.in_blocked4 ? spec_off4(row, col0 + c, p.pitch) : spec_off(row, col0 + c, p.pitch)));
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -704,14 +717,14 @@ RL_HD void colconv_outer4_body(const ColParams<T>& p, int tid, int bx, int by, c
     if constexpr (MODE == COL_PER_IMAGE) {
         const int frame = by / p.V, view = by % p.V;
         Set Y;
-        forward_class(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img, Y, p.tw);
+        forward_class(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img_in, Y, p.tw);
         all_to_all(Y, false);            // Y = X[k + Li g]
         multiply_into(Y, Y, view);
         inverse_class(Y, p.out + (size_t)by * img, p.tw);
     } else if constexpr (MODE == COL_H_MULTI) {
         // by = frame: ONE forward transform of the frame's spectrum (H, ref:573-576), V products + inverse transforms
         Set X, Z;
-        forward_class(p.in + (size_t)by * img, X, p.tw);
+        forward_class(p.in + (size_t)by * img_in, X, p.tw);
         all_to_all(X, false);
         for (int view = 0; view < p.V; ++view) {
             const cx<T>* tw = launder(p.tw);
@@ -725,7 +738,7 @@ RL_HD void colconv_outer4_body(const ColParams<T>& p, int tid, int bx, int by, c
         for (int view = 0; view < p.V; ++view) {
             const cx<T>* tw = launder(p.tw);
             if (view > 0) sync.wg();     // the previous view's exchange has been read
-            forward_class(p.in + ((size_t)by * p.V + view) * img, Y, tw);
+            forward_class(p.in + ((size_t)by * p.V + view) * img_in, Y, tw);
             all_to_all(Y, false);
             multiply_into(Y, Y, view);
             if (colok) {
@@ -766,12 +779,15 @@ struct RowParams {
     // spectra are computed once per plan and every frame's ROW_RATIO reads them.
     int in_mod = 0;
     int sub_one = 0;        // ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE multiplies by max(1 + acc / norm, 0): see rl_ratio
+    int out_blocked4 = 0;   // rowpass_body: spec_out is written in the 4 x 4 blocked layout (spec_off4; image = spec_rows4(ny) rows)
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
-// ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.
-template <class Cfg, int Q, int MODE, bool ONEV, typename T, class Sync>
+// ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.  PRESUM (with ONEV, ROW_UPDATE): p.V
+// spectra per image, summed before the one inverse transform.
+template <class Cfg, int Q, int MODE, bool ONEV, typename T, bool PRESUM = false, class Sync>
 RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
+    static_assert(!PRESUM || (ONEV && MODE == ROW_UPDATE), "PRESUM is a form of the single-spectrum update");
     constexpr int NP = Cfg::NP, L = Cfg::L, TT = Cfg::T;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     const int q = tid / TT, t = tid % TT;
@@ -821,6 +837,9 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 #pragma unroll
             for (int s = 0; s < NB * R; ++s) acc[s] = mk<T>((T)0, (T)0);
         }
+        // PRESUM (`ratio - 1` updates sum the views' residuals as they are and clamp the SUM, rl_update_factor): the transform is
+        // linear, so the p.V spectra of an image are added on their way in and ONE inverse transform serves them all
+        const int nsum = PRESUM ? p.V : 1;
         for (int vw = 0; vw < nview; ++vw) {
             const size_t im = MULTI ? (size_t)by * p.V + vw : (p.in_mod > 0 ? (size_t)(by % p.in_mod) : (size_t)by);
             const cx<T>* __restrict__ sp = p.spec_in + im * simg;
@@ -836,6 +855,32 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 B[it] = mk<T>((T)0, (T)0);
                 if (k <= L / 2 && ok0) A[it] = sp[spec_off(r0, k, p.pitch)];
                 if (k <= L / 2 && ok1) B[it] = sp[spec_off(r1, k, p.pitch)];
+            }
+            if constexpr (PRESUM) {   // the other views, three at a time: their loads are in flight together
+                for (int u0 = 1; u0 < nsum; u0 += 3) {
+                    cx<T> EA[3][NPK], EB[3][NPK];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const cx<T>* __restrict__ su = sp + (size_t)(u0 + j) * simg;
+                        const bool on = u0 + j < nsum;
+#pragma unroll
+                        for (int it = 0; it < NPK; ++it) {
+                            const int k = t + it * TT;
+                            EA[j][it] = mk<T>((T)0, (T)0);
+                            EB[j][it] = mk<T>((T)0, (T)0);
+                            if (on && k <= L / 2 && ok0) EA[j][it] = su[spec_off(r0, k, p.pitch)];
+                            if (on && k <= L / 2 && ok1) EB[j][it] = su[spec_off(r1, k, p.pitch)];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                        for (int it = 0; it < NPK; ++it) {
+                            A[it] = A[it] + EA[j][it];
+                            B[it] = B[it] + EB[j][it];
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int it = 0; it < NPK; ++it) {
@@ -952,15 +997,16 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             }
         }
         fft_sync<Cfg>(sync);
-        cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg;
+        const bool blk = p.out_blocked4 != 0;
+        cx<T>* __restrict__ so = p.spec_out + (size_t)by * (blk ? spec_image_elems(spec_rows4(p.ny), p.pitch) : simg);
         constexpr int NUP = (L / 2 + TT) / TT;
 #pragma unroll
         for (int it = 0; it < NUP; ++it) {
             const int k = t + it * TT;
             if (k <= L / 2) {
                 const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
-                if (ok0) so[spec_off(r0, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
-                if (ok1) so[spec_off(r1, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
+                if (ok0) so[blk ? spec_off4(r0, k, p.pitch) : spec_off(r0, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
+                if (ok1) so[blk ? spec_off4(r1, k, p.pitch) : spec_off(r1, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
             }
         }
         rl_stamp(sync, 5);
@@ -1096,6 +1142,20 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
         }
     }
     fft_sync<Cfg>(sync);
+    if (p.out_blocked4) {   // (ROW_RATIO of a plan whose column length takes the blocked ratio spectra: spec_off4)
+        cx<T>* __restrict__ so = p.spec_out + (size_t)by * spec_image_elems(spec_rows4(p.ny), p.pitch);
+#pragma unroll
+        for (int it = 0; it < NPK; ++it) {
+            const int kk = tl_ + it * 64;
+            if (kk <= L / 2) {
+                const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
+                so[spec_off4(r0, kk, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
+                if (ok1) so[spec_off4(r0 + 1, kk, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
+            }
+        }
+        rl_stamp(sync, 5);
+        return;
+    }
     cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
     cx<T>* __restrict__ so1 = so0 + p.pitch;
 #pragma unroll

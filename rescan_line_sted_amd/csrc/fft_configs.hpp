@@ -181,6 +181,9 @@ struct OuterCol {
 // wave).  History: on colconv_outer_body they hold two 4 x 10 register sets (256 VGPRs + 81 spilled dwords, one workgroup per CU:
 // round 2, H 0.355 -> 0.478 ms per 4-frame launch); on a two-waves-per-column body (round 3) 128 VGPRs + 60-100 spilled dwords,
 // 991 us against 730 us for the V per-image launches.  Both removed.
+#ifndef RL_OUTER_BLOCKED4
+#define RL_OUTER_BLOCKED4 1        // COL_HT_SUM reads its ratio spectra in the 4 x 4 blocked layout (conv_kernels.hpp spec_off4)
+#endif
 #ifndef RL_OUTER_FOUR_WAVES
 #define RL_OUTER_FOUR_WAVES 1      // 1: colconv_outer4_body for the multi-view modes; 2: for the per-image mode too (measured 40 % slower)
 #endif
@@ -198,7 +201,9 @@ struct OuterCol<2304> {
     // COL_H_MULTI on four waves 952; H_t per image 730 + ROW_UPDATE over 4 spectra 732, as COL_HT_SUM on four waves 974 +
     // ROW_UPDATE over one spectrum 179.  So the plan uses the Fourier-domain view sum (bit 1 of KernelTable::col_multi), not the
     // shared forward transform (bit 0: RL_OUTER_H_MULTI).
-    static constexpr int MULTI_MODES = FOUR_WAVES ? (2 | (RL_OUTER_H_MULTI ? 1 : 0)) : 0;
+    // bit 3: only from three views on -- at two, V per-image launches + the pre-summed single-transform update (rowpass_body
+    // PRESUM) are faster: 2048^2, 2 views 386 against 370 frames/s; 4 views 195 against 211
+    static constexpr int MULTI_MODES = FOUR_WAVES ? (2 | 8 | (RL_OUTER_H_MULTI ? 1 : 0) | (RL_OUTER_BLOCKED4 ? 4 : 0)) : 0;
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.

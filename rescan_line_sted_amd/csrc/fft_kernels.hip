@@ -16,6 +16,12 @@
 #ifndef RL_UPD_MIN_WAVES
 #define RL_UPD_MIN_WAVES 1
 #endif
+#ifndef RL_ROWL_RATIO_WAVES
+#define RL_ROWL_RATIO_WAVES 1
+#endif
+#ifndef RL_ROWL_UPD_WAVES
+#define RL_ROWL_UPD_WAVES 1
+#endif
 #ifndef RL_ROW_LEAN
 #define RL_ROW_LEAN 1
 #endif
@@ -150,13 +156,18 @@ static void fill_outer_twiddles(double* out) {
 // waves per SIMD requested from the register allocator (f32, wave-private lengths)
 template <int L, int MODE, bool ONEV, typename T>
 constexpr int row_min_waves() {
-    if (sizeof(T) != 4 || !WavePrivate<typename CfgFor<L>::Cfg>::value) return 1;
+    if (sizeof(T) == 4 && !WavePrivate<typename CfgFor<L>::Cfg>::value) {   // the long lengths (256 threads per transform)
+        if (MODE == ROW_RATIO) return RL_ROWL_RATIO_WAVES;
+        if (MODE == ROW_UPDATE && ONEV) return RL_ROWL_UPD_WAVES;
+        return 1;
+    }
+    if (sizeof(T) != 4) return 1;
     if (MODE == ROW_RATIO) return RL_ROW_MIN_WAVES;
     if (MODE == ROW_UPDATE && ONEV) return RL_UPD_MIN_WAVES;
     return 1;
 }
 
-template <int L, int Q, int MODE, bool ONEV, typename T>
+template <int L, int Q, int MODE, bool ONEV, typename T, bool PRESUM = false>
 __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, ONEV, T>()))
     k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -167,11 +178,11 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, 
     const unsigned bx = blockIdx.x, by = blockIdx.y;
     // single-view RL modes of the wave-private lengths: the lean item code (scalar row bases,
     // unconditional loads).  RATIO treats every (frame, view) image on its own, so it always qualifies.
-    constexpr bool LEAN = RL_ROW_LEAN && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
+    constexpr bool LEAN = RL_ROW_LEAN && !PRESUM && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
     if constexpr (LEAN)
         rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
-        rowpass_body<KCfg, Q, MODE, ONEV, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
+        rowpass_body<KCfg, Q, MODE, ONEV, T, PRESUM>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
 
 template <int C, typename T>
@@ -239,6 +250,12 @@ template <int Q, int MODE, typename T>
 static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
     constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
+    if constexpr (MODE == ROW_UPDATE) {
+        if (p.V > 1 && p.sub_one) {   // the views' residual spectra are summed on their way in: one inverse transform (rowpass_body PRESUM)
+            rl_launch(k_rowpass<RL_CFG_L, Q, MODE, true, T, true>, dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s, p);
+            return hipGetLastError();
+        }
+    }
     if (MULTI && p.V == 1)   // single view: variant without accumulator registers
         rl_launch(k_rowpass<RL_CFG_L, Q, MODE, MULTI, T>, dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s, p);
     else

@@ -22,7 +22,9 @@ struct KernelTable {
     int Q[2];         // row pairs per workgroup in the row kernels, per dtype
     // per dtype (the f32 and f64 column kernels of a length may be different kernels):
     int psf_transposed[2];   // column kernel reads psf_hat as [view][Kx][L] (one wave per column)
-    int col_multi[2];        // multi-view column modes the plan should use: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM
+    int col_multi[2];        // multi-view column modes the plan should use: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM,
+                             // bit 2 COL_HT_SUM wants its input in the 4 x 4 blocked layout (ColParams::in_blocked4),
+                             // bit 3 COL_HT_SUM only for three views or more
     int tw_count;         // complex entries of the per-pass twiddle table (fft_core.hpp PassTw), row kernels
     void (*fill_tw)(double* out);   // host: writes 2*tw_count doubles (re, im interleaved)
     int tw_count_col[2];  // the same for the column kernels (their geometry may differ: fft_configs.hpp ColCfgFor)

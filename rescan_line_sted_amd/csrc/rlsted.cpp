@@ -76,6 +76,7 @@ struct rl_deconv {
     double psf_hat_imag_ratio = 0;   // max |im| / max |z| of the PSF spectrum
     void* spec_a = nullptr;    // [B] spectrum images (layout: conv_kernels.hpp spec_off)
     void* spec_b = nullptr;    // [B*V] spectrum images
+    void* spec_c = nullptr;    // [B*V] ratio spectra in the 4 x 4 blocked layout (blocked4() plans only)
     void* spec_ones = nullptr; // [V] column-transformed spectra of H(estimate = 1): the same for every frame (ref:522)
     // storage-precision study builds (conv_kernels.hpp RL_SPEC_QUANT): powers of two that bring the DC term of an
     // estimate-type / ratio-type spectrum to 2^14 (RLSTED_Q_EXP_EST / RLSTED_Q_EXP_RATIO = log2 of the DC bound)
@@ -335,8 +336,12 @@ struct rl_deconv {
 
     bool col_multi = true;   // RLSTED_COL_MULTI=0 (A/B knob): V per-image column launches even where the multi-view modes exist
     // KernelTable::col_multi: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM.  wave_private_y(): the Fourier-domain view sum exists (and is wanted)
-    bool wave_private_y() const { return col_multi && (ty->col_multi[dtype] & 2) != 0; }
+    bool wave_private_y() const { return col_multi && (ty->col_multi[dtype] & 2) != 0 && (V >= 3 || !(ty->col_multi[dtype] & 8)); }
     bool h_multi() const { return col_multi && (ty->col_multi[dtype] & 1) != 0; }
+    // ROW_RATIO writes the ratio spectra into spec_c in the 4 x 4 blocked layout, COL_HT_SUM reads them there (RLSTED_BLOCKED4=0: A/B knob)
+    bool blocked4_wanted = true;
+    bool blocked4() const { return blocked4_wanted && V > 1 && fuse_views && wave_private_y() && (ty->col_multi[dtype] & 4) != 0; }
+    size_t n_spec4() const { return spec_image_elems(spec_rows4(ny), pitch); }
     bool psf_transposed() const { return ty->psf_transposed[dtype] != 0; }   // psf_hat is [view][Kx][Ly]
     template <typename T>
     int col_t(const void* in, void* out, int frames, ColKind kind) {
@@ -357,6 +362,7 @@ struct rl_deconv {
             gy = (unsigned)frames;
         } else if (V > 1 && kind == COL_HT_FUSED && wave_private_y()) {
             p.mode = COL_HT_SUM;
+            p.in_blocked4 = blocked4() ? 1 : 0;
             gy = (unsigned)frames;
         } else if (kind == COL_HT_FUSED && V > 1) {
             return fail(RL_ERR_STATE, "internal: fused H_t needs a wave-private column transform");
@@ -382,11 +388,12 @@ struct rl_deconv {
     static constexpr int kMaxGridY = 65535;
     int col(const void* in, void* out, int frames, ColKind kind) {
         const size_t sp = n_spec() * 2 * esize(dtype);   // bytes of one spectrum image
+        const size_t sp_in = kind == COL_HT_FUSED && blocked4() ? n_spec4() * 2 * esize(dtype) : sp;
         const size_t in_per = kind == COL_H ? 1 : (size_t)V, out_per = kind == COL_HT_FUSED ? 1 : (size_t)V;
         const int step = std::max(1, kMaxGridY / V);
         for (int f0 = 0; f0 < frames; f0 += step) {
             const int nf = std::min(step, frames - f0);
-            const void* i = (const char*)in + (size_t)f0 * in_per * sp;
+            const void* i = (const char*)in + (size_t)f0 * in_per * sp_in;
             void* o = (char*)out + (size_t)f0 * out_per * sp;
             RL_TRY(dtype == RL_F32 ? col_t<float>(i, o, nf, kind) : col_t<double>(i, o, nf, kind));
         }
@@ -395,9 +402,10 @@ struct rl_deconv {
     int col(const void* in, void* out, int frames, bool h_mode) { return col(in, out, frames, h_mode ? COL_H : COL_HT_VIEW); }
     template <typename T>
     int row_t(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-              const void* scale, int views, int in_mod = 0) {
+              const void* scale, int views, int in_mod = 0, bool out_blocked = false) {
         RowParams<T> p;
         p.in_mod = in_mod;
+        p.out_blocked4 = out_blocked ? 1 : 0;
         p.sub_one = sub_one ? 1 : 0;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
@@ -425,9 +433,10 @@ struct rl_deconv {
         return RL_OK;
     }
     int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-            const void* scale = nullptr, int views = -1, int in_mod = 0) {
+            const void* scale = nullptr, int views = -1, int in_mod = 0, bool out_blocked = false) {
         if (views < 0) views = V;
         const size_t sp = n_spec() * 2 * esize(dtype), im = n_img() * esize(dtype);
+        const size_t sp_out = (out_blocked ? n_spec4() : n_spec()) * 2 * esize(dtype);
         const bool multi = mode == ROW_UPDATE || mode == ROW_ADJ;   // `views` input spectra per image
         const unsigned piece = in_mod > 0 ? (unsigned)(kMaxGridY / in_mod * in_mod) : (unsigned)kMaxGridY;
         for (unsigned g0 = 0; g0 < gy; g0 += piece) {
@@ -435,12 +444,12 @@ struct rl_deconv {
             // (kMaxGridY is a multiple of every in_mod in use only by accident: a shared input is not moved on,
             // and the image index restarts at 0 in each piece -- so pieces must start on a multiple of in_mod)
             const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)g0 * (multi ? (size_t)views : 1) * sp) : nullptr;
-            void* so = spec_out ? (char*)spec_out + (size_t)g0 * sp : nullptr;
+            void* so = spec_out ? (char*)spec_out + (size_t)g0 * sp_out : nullptr;
             const void* sr = src ? (const char*)src + (size_t)g0 * im : nullptr;
             void* ds = dst ? (char*)dst + (size_t)g0 * im : nullptr;
             const void* sc = scale ? (const char*)scale + (size_t)g0 * esize(dtype) : nullptr;
-            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod)
-                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod));
+            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod, out_blocked)
+                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod, out_blocked));
         }
         return RL_OK;
     }
@@ -598,15 +607,19 @@ struct rl_deconv {
             RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
             return RL_OK;
         }
+        // (blocked4(): the ratio spectra go to spec_c in the layout COL_HT_SUM's four-column tiles read whole lines of -- not in
+        // place, a row pair's 4 x 4 blocks hold rows other workgroups have yet to read)
+        const bool blk = blocked4();
+        void* sr = blk ? off(spec_c, (size_t)f0 * V * n_spec4() * 2) : sb;
         if (first) {
-            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V));
+            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sr, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V, blk));
         } else {
             RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
-            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
+            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sr, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, 0, blk));   // meas / H(est)
         }
         if (fuse_views && V > 1 && wave_private_y()) {
             // views summed in the Fourier domain: one inverse column + one inverse row transform per frame
-            RL_TRY(col(sb, sa, nf, COL_HT_FUSED));
+            RL_TRY(col(sr, sa, nf, COL_HT_FUSED));
             RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm, nullptr, 1));
         } else {
             RL_TRY(col(sb, sb, nf, false));                                                                  // H_t, column part
@@ -812,7 +825,7 @@ int rl_deconv_destroy(rl_deconv* h) {
     hipStreamSynchronize(h->ctx->stream);
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
         if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
-    void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
+    void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->spec_c, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -856,6 +869,12 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         {&h->noiseless, B * V * h->n_img() * es},     {&h->meas, B * V * h->n_img() * es},
         {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
         {&h->scratch, std::max(B * V * h->n_img() * es, aux_poisson_workspace_bytes(B * V * h->n_img()))}};   // also the Poisson work list
+    if (h->blocked4()) {   // (rows 4 * (ny / 4) .. of the last block row are never written when ny % 4 != 0 -- and never read)
+        const size_t n = B * V * h->n_spec4() * 2 * es;
+        HIP_TRY(hipMalloc(&h->spec_c, n + RL_STREAM_SLACK));
+        HIP_TRY(hipMemsetAsync(h->spec_c, 0, n + RL_STREAM_SLACK, ctx->stream));
+        h->bytes += n + RL_STREAM_SLACK;
+    }
     for (const Req& r : reqs) {
         // RL_STREAM_SLACK: the streaming row kernels load whole 64-lane segments without clamping;
         // lanes past the end of the last row of a buffer read (and discard) these bytes
@@ -1105,6 +1124,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
         if (h->lanes < 1) h->lanes = 1;
         if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
     }
+    if (getenv("RLSTED_BLOCKED4")) h->blocked4_wanted = atoi(getenv("RLSTED_BLOCKED4")) != 0;
     if (getenv("RLSTED_COL_MULTI")) h->col_multi = atoi(getenv("RLSTED_COL_MULTI")) != 0;
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     h->exact_norm = getenv("RLSTED_EXACT_NORM") ? atoi(getenv("RLSTED_EXACT_NORM")) != 0 : (dtype == RL_F32);
@@ -1467,11 +1487,12 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
                 case 0: RL_TRY(h->col(h->spec_a, one_buffer ? h->spec_a : h->spec_b, nf, true)); break;
                 case 1:
                     if (one_buffer) RL_TRY(h->row(ROW_RATIO, (unsigned)nf, h->spec_a, h->spec_a, h->meas, nullptr, nullptr));
-                    else RL_TRY(h->row(ROW_RATIO, (unsigned)(nf * h->V), h->spec_b, h->spec_b, h->meas, nullptr, nullptr));
+                    else RL_TRY(h->row(ROW_RATIO, (unsigned)(nf * h->V), h->spec_b, h->blocked4() ? h->spec_c : h->spec_b, h->meas, nullptr, nullptr,
+                                       nullptr, -1, 0, h->blocked4()));
                     break;
                 case 2:   // as iterate_chunk(): in place, fused (Fourier-domain view sum) or per view
                     if (one_buffer) RL_TRY(h->col(h->spec_a, h->spec_a, nf, false));
-                    else if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->spec_b, h->spec_a, nf, rl_deconv::COL_HT_FUSED));
+                    else if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->blocked4() ? h->spec_c : h->spec_b, h->spec_a, nf, rl_deconv::COL_HT_FUSED));
                     else RL_TRY(h->col(h->spec_b, h->spec_b, nf, false));
                     break;
                 case 3:

@@ -127,7 +127,13 @@ static int row_m(const RowParams<T>& p, int gy) {
                          return;
                      }
                  }
-                 if (MULTI && p.V == 1)   // same dispatch as launch_row_m in fft_kernels.hip
+                 if constexpr (MODE == ROW_UPDATE) {
+                     if (p.V > 1 && p.sub_one) {   // same dispatch as launch_row_m in fft_kernels.hip
+                         rowpass_body<Cfg, Q, MODE, true, T, true>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                         return;
+                     }
+                 }
+                 if (MULTI && p.V == 1)
                      rowpass_body<Cfg, Q, MODE, MULTI, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
                  else
                      rowpass_body<Cfg, Q, MODE, false, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
@@ -138,6 +144,8 @@ static int row_m(const RowParams<T>& p, int gy) {
 // RowParams::sub_one of every row launch (conv_kernels.hpp rl_ratio: ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE
 // multiplies by max(1 + acc / norm, 0))
 static int g_sub_one = 0;
+// RowParams::out_blocked4 of every row launch / ColParams::in_blocked4 of every four-wave column launch (conv_kernels.hpp spec_off4)
+static int g_blocked4 = 0;
 
 template <int L, typename T>
 static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, const T* scale,
@@ -145,6 +153,7 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
     auto tw = twiddles<L, T>();
     RowParams<T> p;
     p.sub_one = g_sub_one;
+    p.out_blocked4 = g_blocked4;
     p.spec_in = reinterpret_cast<const cx<T>*>(spec_in);
     p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
     p.src = src; p.dst = dst; p.norm = norm; p.scale = scale; p.tw = tw.data();
@@ -171,6 +180,7 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
 extern "C" {
 
 void emu_set_sub_one(int on) { g_sub_one = on; }
+void emu_set_blocked4(int on) { g_blocked4 = on; }
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
@@ -260,6 +270,7 @@ static int col_outer4_t(const T* in, T* out, const T* psf_hat, int real_psf, int
     p.tw = tw.data();
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
     p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
+    p.in_blocked4 = g_blocked4;
     if constexpr (WAVES == 4) {
         run_grid((kx + C - 1) / C, p.images, 256 * C, (size_t)4 * C * LdsSlots<Core>::value * sizeof(cx<T>),
                  [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {

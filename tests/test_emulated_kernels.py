@@ -300,12 +300,14 @@ def test_golden_rl_through_emulated_kernels(emu, golden):
     assert (np.abs(est[0] - ref) / np.abs(ref)).max() < 1e-9
 
 
-@pytest.mark.parametrize('Ly,Lx,V,fuse', [(256, 256, 1, False), (64, 192, 2, False), (256, 256, 3, True), (64, 64, 2, False)])
+@pytest.mark.parametrize('Ly,Lx,V,fuse', [(256, 256, 1, False), (64, 192, 2, False), (256, 256, 3, True), (64, 64, 2, False),
+                                          (64, 64, 5, False)])
 def test_ratio_minus_one_iteration(emu, Ly, Lx, V, fuse):
     """RowParams::sub_one (the f32 plans' default, conv_kernels.hpp rl_ratio): ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE
     multiplies by max(1 + sum_v conv(ratio_v - 1, p_v) / norm, 0).  In float64 that is the plain iteration to rounding,
-    through the lean single-view bodies (256), the generic multi-view body (192 / 64: views summed raw, the sum clamped)
-    and the Fourier-domain view sum."""
+    through the lean single-view bodies (256), the multi-view update (192 / 64: rowpass_body PRESUM adds the views' spectra on
+    their way in -- three at a time, so 2 and 5 views -- and clamps the sum after the one inverse transform) and the
+    Fourier-domain view sum."""
     emu.emu_set_sub_one.argtypes = [ctypes.c_int]
     rng = np.random.default_rng(11 + V)
     ny, nx = 21, 30
@@ -406,6 +408,72 @@ def test_outer_decimation_four_waves_per_column(emu, Li, C, mode, ny, kx, real_p
         else:
             ref = np.fft.ifft(sum(spec[f * V + v] * ph[v].T for v in range(V)), axis=0)[:ny] * L
             assert max_rel(out[f][:, :kx], ref) < 1e-12, f
+
+
+def _blocked4(x):
+    """Row-major spectra (n, ny, pitch) -> the 4 x 4 blocked layout of conv_kernels.hpp spec_off4 (rows padded to a multiple of 4)."""
+    n, ny, pitch = x.shape
+    r4 = (ny + 3) // 4 * 4
+    full = np.full((n, r4, pitch), np.nan, dtype=x.dtype)
+    full[:, :ny] = x
+    return np.ascontiguousarray(full.reshape(n, r4 // 4, 4, pitch // 4, 4).transpose(0, 1, 3, 2, 4)).reshape(n, r4, pitch)
+
+
+@pytest.mark.parametrize('Li,C,ny,kx,real_psf', [(256, 4, 1001, 6, 1), (576, 1, 2048, 1, 0), (256, 2, 603, 3, 1)])
+def test_four_wave_view_sum_reads_blocked_ratio_spectra(emu, Li, C, ny, kx, real_psf):
+    """ColParams::in_blocked4: COL_HT_SUM of colconv_outer4_body takes its input in the 4 x 4 blocked layout (one 128-byte line
+    = 4 rows x 4 columns, so the four wave groups of a workgroup share the lines they fetch) and gives the row-major result
+    of the row-major input; heights that are not multiples of 4, partial column tiles."""
+    emu.emu_set_blocked4.argtypes = [ctypes.c_int]
+    L, V, frames = 4 * Li, 3, 2
+    pitch = (kx + 7) // 8 * 8
+    rng = np.random.default_rng(Li + ny + C)
+    x = np.zeros((frames * V, ny, pitch), dtype=np.complex128)
+    x[:, :, :kx] = rng.standard_normal((frames * V, ny, kx)) + 1j * rng.standard_normal((frames * V, ny, kx))
+    ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
+    psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
+    outs = []
+    for blocked in (0, 1):
+        out = np.full((frames, ny, pitch), np.nan + 0j, dtype=np.complex128)
+        try:
+            emu.emu_set_blocked4(blocked)
+            rc = emu.emu_col_outer4_f64(Li, C, 2, _p(_slack(_blocked4(x) if blocked else x)), _p(out), _p(psf_arg), real_psf, ny, kx,
+                                        pitch, V, frames, 1, 0)
+        finally:
+            emu.emu_set_blocked4(0)
+        assert rc == 0
+        outs.append(out[:, :, :kx])
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('Lx,ny,nx', [(192, 7, 150), (256, 10, 200), (576, 5, 512)])
+def test_ratio_rows_store_the_blocked_layout(emu, Lx, ny, nx):
+    """RowParams::out_blocked4: ROW_RATIO writes the same values, at spec_off4 -- the generic body (192) and the lean one (256, 576)."""
+    emu.emu_set_blocked4.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(Lx + ny)
+    pl = EmuPlan(emu, [np.ones((1, 3, 3)) / 9], ny, nx, 64, Lx)
+    gy = 3
+    sin = pl.spec(gy)
+    rows = np.zeros((gy, ny, Lx))
+    rows[:, :, :nx] = rng.random((gy, ny, nx)) + 0.5                 # a positive H(est), so that the ratio is finite
+    sin[...] = 0
+    sin[:, :, :pl.kx] = np.fft.rfft(rows, axis=2) / Lx
+    meas = _slack(rng.random((gy, ny, nx)) * 30)
+    plain = pl.spec(gy)
+    pl._row(ROW_RATIO, gy, sin, plain, meas, None, None, None)
+    r4 = (ny + 3) // 4 * 4
+    blk = _slack(np.full((gy, r4, pl.pitch), np.nan + 0j, dtype=np.complex128))
+    try:
+        emu.emu_set_blocked4(1)
+        pl._row(ROW_RATIO, gy, sin, blk, meas, None, None, None)
+    finally:
+        emu.emu_set_blocked4(0)
+    want = np.full((gy, ny, pl.pitch), np.nan + 0j)
+    want[:, :, :pl.kx] = plain[:, :, :pl.kx]
+    got = _blocked4(want)
+    mask = np.isfinite(got)                      # (columns >= kx and the pad rows: never written, whatever the layout)
+    assert mask.sum() == gy * ny * pl.kx and np.array_equal(blk[mask], got[mask])
+    assert np.isnan(blk[~mask]).all()
 
 
 # ------------------------------------------------- frame pairs: two frames in one complex image

@@ -107,6 +107,29 @@ def test_large_tiles_f32_vs_f64_plan(lib, golden, size):
         assert errs[100] < 4 * errs[20], errs           # growth is sub-linear now (was 5x for 5x the iterations)
 
 
+@pytest.mark.parametrize('ny,nx,views', [(2048, 2048, 2), (1024, 1024, 4), (2048, 2048, 5), (600, 4096, 3)])
+def test_multi_view_long_transforms_f32_vs_f64_plan(lib, golden, ny, nx, views):
+    """Multi-view plans on the long transforms, f32 against the f64 plan (same noisy measurement, K = 20).  Two views at
+    L = 2304, and every view count at 1152 / 4608, run V per-image column launches and the pre-summed update (rowpass_body
+    PRESUM: the views' `ratio - 1` spectra are added on their way in, ONE inverse row transform, the sum clamped); three
+    views or more at L = 2304 the Fourier-domain view sum over the 4 x 4 blocked ratio spectra (colconv_outer4_body)."""
+    g = golden('g8_fig2_psfs')
+    base = g['2p0x_lr/line_sted_psfs'][:, 0]
+    psfs = [np.roll(base[v % len(base)], v // len(base), axis=1)[None] for v in range(views)]
+    obj = np.random.default_rng(ny + views).random((1, ny, nx)) * 255
+    p64 = lib.DeconvPlan(psfs, 1, ny, nx, dtype='f64')
+    p64.set_object(obj, 5e10 * ny * nx / 128 ** 2)
+    p64.simulate(seed=3)
+    p32 = lib.DeconvPlan(psfs, 1, ny, nx, dtype='f32')
+    p32.set_object(obj, 5e10 * ny * nx / 128 ** 2)
+    p32.set_measurement(p64.measurement())
+    p64.iterate(20)
+    p32.iterate(20)
+    err = max_rel(p32.estimate()[0], p64.estimate()[0])
+    print('f32 vs f64, %d x %d, %d views: %.2e' % (ny, nx, views, err))
+    assert err < F32_MARGIN, err
+
+
 @pytest.mark.parametrize('size', [2048, 4096])
 def test_frame_pairs_on_the_long_transforms(lib, golden, size, monkeypatch):
     """L = 2304 / 4608 (one workgroup-synchronous row transform per workgroup): the frame-pair loop (the default for f32
