@@ -78,7 +78,7 @@ def build_variant(name, verbose=False):
         OBJ = os.path.join(ROOT, 'build', 'obj_' + name)
         LIB = os.path.join(LIBDIR, 'librlsted_%s.so' % name)
         DEVICE = DEVICE + VARIANTS[name]
-        return build(force=False, verbose=verbose)
+        return build(force=name.startswith('ab'), verbose=verbose)   # (the scratch builds' flags change between runs)
     finally:
         OBJ, LIB, DEVICE = keep
 

@@ -91,16 +91,6 @@ RL_HD cx<T> rl_spec_round(cx<T> v, float qscale) {
 // pair -- was built and measured in round 1: the column kernel's fabric reads did not change, 1.1 % slower; removed.)
 RL_HD size_t spec_image_elems(int ny, int pitch) { return (size_t)ny * pitch; }
 RL_HD size_t spec_off(int row, int col, int pitch) { return (size_t)row * pitch + col; }
-// The 4 x 4 blocked layout of the ratio spectra that feed colconv_outer4_body's COL_HT_SUM (round 3): element (row, col) at
-//     ((row / 4) * (pitch / 4) + col / 4) * 16 + (row % 4) * 4 + col % 4
-// -- 4 rows x 4 columns = one 128-byte line (f32).  That body reads 4-column tiles, residue class row % 4 = g by wave group g:
-// in row-major order every 32-byte piece it needs sits in a line of its own row and 3/4 of each fetched line is thrown away
-// (PMC: 465 MB of fabric traffic per 2048^2 frame against 137 MB of spectra and multipliers); blocked, the four wave groups of
-// ONE workgroup read the four pieces of the same line.  The image then holds (ny rounded up to 4) rows.
-RL_HD int spec_rows4(int ny) { return (ny + 3) & ~3; }
-RL_HD size_t spec_off4(int row, int col, int pitch) {
-    return ((size_t)(row >> 2) * (pitch >> 2) + (col >> 2)) * 16 + ((row & 3) << 2) + (col & 3);
-}
 
 // ------------------------------ column pass --------------------------------
 // For one tile of C spectrum columns: forward FFT along y (rows >= ny are
@@ -121,7 +111,9 @@ struct ColParams {
     // psf_hat ([view][kx][L]); used by the REALP instantiations of the wave-private column kernel
     // (half the multiplier bytes, a real x complex product).  nullptr: the complex multiplier.
     const T* psf_hat_re = nullptr;
-    int in_blocked4 = 0;    // colconv_outer4_body: the input images are in the 4 x 4 blocked layout (spec_off4)
+    // the split column pass: column spectra in register-slot order (colconv_outer_body: outer_slots_image_elems per image)
+    const cx<T>* xs_in = nullptr;   // COL_SPLIT_INV: image frame*in_sb + view*in_sv; COL_SPLIT_INV_SUM: images frame*V + v
+    cx<T>* xs_out = nullptr;        // COL_SPLIT_FWD: one per launch row
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
@@ -209,7 +201,10 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
 //                  in the Fourier domain and inverse transformed once -> output image frame
 //                  (H_t, ref:584-588, with the per-view clamp replaced by one clamp of the sum:
 //                  identical in exact arithmetic, see DESIGN.md "fused views")
-enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2 };
+enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
+               // the split column pass of colconv_outer_body (round 3): forward half -> column spectra in register-slot order,
+               // inverse half from there -- one image per launch row, or the V views of a frame summed
+               COL_SPLIT_FWD = 3, COL_SPLIT_INV = 4, COL_SPLIT_INV_SUM = 5 };
 
 // MODE is a compile-time parameter: each mode is its own kernel, so the single-view path
 // does not inherit the register footprint of the multi-view loops.
@@ -522,6 +517,13 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     _Pragma("unroll") for (int s = 0; s <= NV; ++s)           \
         if ((s != NV || FL::TAIL) && slot_live(s))
 
+    // The SPLIT pass (round 3): the column spectrum X[k + Li j] of an image parked in global memory in the order the lanes hold
+    // it -- [tile][slot s][j][wave][lane], every access one contiguous 512-byte row per wave, no LDS, no barrier -- between a
+    // forward launch and an inverse launch.  Multi-view plans then transform a frame's spectrum ONCE for its V views (H: 1 + V
+    // transforms per column instead of 2 V) and sum the views' products slot by slot before ONE inverse transform (H_t: V + 1),
+    // with one register set: neither half keeps a second set alive the way the fused multi-view modes must.
+    const size_t xs_img = (size_t)((p.kx + C - 1) / C) * (NV + 1) * M * NT;
+    auto xs_at = [&](int s, int j) -> size_t { return (((size_t)bx * (NV + 1) + s) * M + j) * NT + tid; };
     if constexpr (MODE == COL_PER_IMAGE) {
         const int frame = by / p.V, view = by % p.V;
         Regs Y;
@@ -534,221 +536,70 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
             }
         }
         inverse_classes(Y, p.out + (size_t)by * img);
+    } else if constexpr (MODE == COL_SPLIT_FWD) {
+        Regs Y;
+        forward_classes(p.in + (size_t)by * img, Y, true);
+        cx<T>* __restrict__ xs = p.xs_out + (size_t)by * xs_img;
+        if (colok) {
+            RL_FOR_LIVE_SLOTS(s) {
+                const int k = slot_index(s);
+                cx<T> u[M];
+                u[0] = Y[0][s];
+#pragma unroll
+                for (int q = 1; q < M; ++q) u[q] = cmul(Y[q][s], ctw[(q - 1) * Li + k]);
+                dft<M, false>(u);
+#pragma unroll
+                for (int j = 0; j < M; ++j) xs[xs_at(s, j)] = u[j];
+            }
+        }
+    } else if constexpr (MODE == COL_SPLIT_INV || MODE == COL_SPLIT_INV_SUM) {
+        const int frame = MODE == COL_SPLIT_INV ? by / p.V : by, view0 = MODE == COL_SPLIT_INV ? by % p.V : 0;
+        const int nv = MODE == COL_SPLIT_INV ? 1 : p.V;
+        const cx<T>* __restrict__ xs0 = p.xs_in + (size_t)(MODE == COL_SPLIT_INV ? frame * p.in_sb + view0 * p.in_sv : frame * p.V) * xs_img;
+        Regs Z;   // [j][s]: the products' sum X[k + Li j] first, then -- slot by slot, in place -- the classes' spectra
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+#pragma unroll
+            for (int s = 0; s <= NV; ++s) Z[j][s] = mk<T>((T)0, (T)0);
+        }
+        if (colok) {
+            for (int v = 0; v < nv; ++v) {   // (all of a view's loads are independent: they are in flight together)
+                const cx<T>* __restrict__ xs = xs0 + (size_t)v * xs_img;
+                const size_t pcol = ((size_t)(view0 + v) * p.kx + col) * L;
+                RL_FOR_LIVE_SLOTS(s) {
+                    const int k = slot_index(s);
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        const cx<T> x = xs[xs_at(s, j)];
+                        if constexpr (REALP) Z[j][s] = Z[j][s] + scale(x, p.psf_hat_re[pcol + k + Li * j]);
+                        else Z[j][s] = Z[j][s] + cmul(x, p.psf_hat[pcol + k + Li * j]);
+                    }
+                }
+            }
+            RL_FOR_LIVE_SLOTS(s) {
+                cx<T> u[M];
+#pragma unroll
+                for (int j = 0; j < M; ++j) u[j] = Z[j][s];
+                slot_classes(u, s, Z);
+            }
+        }
+        inverse_classes(Z, p.out + (size_t)by * img);
     } else {
-        static_assert(MODE == COL_PER_IMAGE, "the multi-view modes of the long transforms live in colconv_outer4_body");
+        static_assert(MODE == COL_PER_IMAGE, "the long transforms have no fused multi-view modes: the split pass serves them");
     }
 #undef RL_FOR_LIVE_SLOTS
 }
-
-// ---------------------------------------------------------------------------------------------
-// FOUR WAVES PER COLUMN (round 3; L = 4 * Li): wave g of a column owns residue class g on the image side and the
-// quarter j = g of the column spectrum, X[k + Li g], on the spectrum side; the radix-4 step is an all-to-all among
-// the column's four waves through LDS (each writes its 9 values per lane, reads the three others':  (-i)^(q g) are
-// sign flips and swaps).  Per wave ONE register set (9 complex values per lane) -- so COL_H_MULTI / COL_HT_SUM hold
-// their persistent quarter beside the working set (colconv_outer_body's multi-view modes needed two 4 x 10 sets per lane:
-// 256 registers + spills; a two-waves-per-column form, built and measured in round 3, still spilled 60-100 registers in the
-// multi-view modes and lost to V per-image launches; its per-image mode, generalised to M = 8 with four classes per wave
-// (16 waves per CU at 4608 instead of 8) and with the next round's rows prefetched, ran 20-30 % SLOWER than colconv_outer_body
-// at both lengths -- 2048^2 530 against 684 frames/s, 4096^2 K = 100 19.4 against 28.2: all removed) -- and per image ONE load phase and ONE store phase over whole tile rows
-// and 6 workgroup barriers (16 in colconv_outer_body).  Workgroup = 4 C waves (C = 4 columns: 1024 threads, 32-byte row
-// segments, one workgroup per CU), LDS = 4 C core regions.  Measured at 2048^2 (fft_configs.hpp OuterCol<2304>): the
-// per-image mode is 40 % SLOWER than colconv_outer_body (one workgroup per CU: its load, transform and store phases do not
-// overlap with another workgroup's), COL_HT_SUM + the single-spectrum ROW_UPDATE it allows beat V per-image launches by 21 %.
-template <class Cfg, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, class Sync>
-RL_HD void colconv_outer4_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
-    static_assert(Cfg::T == 64, "the core must be a wave-private transform");
-    constexpr int M = 4, NP = Cfg::NP, Li = Cfg::L, L = M * Li, LP = LdsSlots<Cfg>::value;
-    constexpr int NG = 64 * C;                           // threads of one class group: they move their class of the tile
-    static_assert((Li * C) % NG == 0, "a class tile must divide evenly over its group");
-    constexpr int NLD = (Li * C) / NG;
-    using FL = PassInfo<Cfg, false, NP - 1>;
-    using IL = PassInfo<Cfg, true, NP - 1>;
-    static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
-    constexpr int NV = FL::NBM * FL::R;                  // lane-local register slots of one core transform
-    constexpr int NS = NV + (FL::TAIL ? 1 : 0);          // ... and the tail element
-    constexpr int VMAX = CfgRegs<Cfg>::VMAX;
-    constexpr int LIVE = FL::NBF < 64 ? FL::NBF : 64;    // lanes that hold values in the spectrum-side register layout
-    static_assert(NV <= VMAX && NS * LIVE <= LP, "a wave's LDS region must hold one register set");
-    constexpr int CTW = PassTw<Cfg, false, 0>::TOTAL;    // W_L^(q k) at tw[CTW + (q - 1) * Li + k]
-    const int w = rl_uniform(tid / 64), lane = tid % 64;
-    const int g = w / C, cw = w % C;                     // class / spectrum quarter, and column, of this wave
-    const int col0 = bx * C, col = col0 + cw;
-    const bool colok = col < p.kx;
-    const size_t img = spec_image_elems(p.ny, p.pitch);                                           // output images (row-major)
-    const size_t img_in = p.in_blocked4 ? spec_image_elems(spec_rows4(p.ny), p.pitch) : img;     // input images
-    LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
-    cx<T>* __restrict__ const mine = lds + w * LP;
-    cx<T>* __restrict__ const group_lds = lds + g * C * LP;      // the regions of this class group: its tile
-    const cx<T>* __restrict__ const column_lds = lds + cw * LP;  // the regions of this column: wave q's at + q * C * LP
-    const int th = tid - g * NG;
-    // the multi-view loops hand the lambdas a twiddle pointer the optimiser cannot see through, or it hoists every
-    // (view-invariant) twiddle load out of the view loop -- ~60 registers
-    auto launder = [](const cx<T>* q) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+s"(q));
-#endif
-        return q;
-    };
-
-    // class g of the tile: element e = th + it*NG <-> (m = e / C, column c = e % C), image row 4 m + g
-    auto load_class = [&](const cx<T>* __restrict__ in) {
-        cx<T> x[NLD];
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = th + it * NG;
-            const int row = M * (e / C) + g, c = e % C;
-            x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx)
-                x[it] = rl_ldg(sync, in + (p.in_blocked4 ? spec_off4(row, col0 + c, p.pitch) : spec_off(row, col0 + c, p.pitch)));
-        }
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = th + it * NG;
-            group_lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
-        }
-    };
-    auto store_class = [&](cx<T>* __restrict__ out) {
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = th + it * NG;
-            const int row = M * (e / C) + g, c = e % C;
-            if (row < p.ny && col0 + c < p.kx)
-                out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(group_lds[c * LP + view_lds.nat(e / C)], p.qscale);
-        }
-    };
-    auto slot_index = [&](int s) -> int {   // element index (within the core transform) of register slot s; s == NV: the tail element
-        if (s == NV) return (64 + (lane & 7)) + bitrev3(lane >> 3) * FL::NBF;
-        return (lane + (s / FL::R) * 64) + (s % FL::R) * FL::NBF;
-    };
-    auto slot_live = [&](int s) -> bool { return s == NV ? true : (lane + (s / FL::R) * 64) < FL::NBF; };
-#define RL_FOR_LIVE_SLOTS(s)                                  \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s)            \
-        if (slot_live(s))
-    // x * (-i)^n (forward) or (+i)^n (inverse), n = 0 .. 3 (wave uniform)
-    auto times_i_pow = [&](cx<T> x, int n, bool inv) -> cx<T> {
-        n &= 3;
-        if (n == 0) return x;
-        if (n == 2) return mk<T>(-x.re, -x.im);
-        return ((n == 1) != inv) ? rot90<false>(x) : rot90<true>(x);   // forward n = 1: -i; inverse n = 1: +i; n = 3: the other one
-    };
-    using Set = cx<T>[NS];
-
-    // Y <- W_L^(g k) * core transform of residue class g of image `in`.  Barriers: the caller's before the load (LDS
-    // free), one after it.
-    auto forward_class = [&](const cx<T>* __restrict__ in, Set& Y, const cx<T>* tw) {
-        load_class(in);
-        sync.wg();
-        cx<T> v[VMAX];
-        cx<T> tl = mk<T>((T)0, (T)0);
-        if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw, sync);
-#pragma unroll
-        for (int s = 0; s < NV; ++s) Y[s] = v[s];
-        if constexpr (FL::TAIL) Y[NV] = tl;
-        if (colok && g > 0) {
-            RL_FOR_LIVE_SLOTS(s) Y[s] = cmul(Y[s], tw[CTW + (g - 1) * Li + slot_index(s)]);
-        }
-    };
-    // all-to-all among the four waves of the column: R[s] <- sum_q (-+i)^(q g) S_q[s].  The wave's own region must be
-    // free of other readers (caller's barrier, or nothing when only this wave has used it since the last barrier).
-    auto all_to_all = [&](Set& S, bool inv) {
-        if (colok) {
-            sync.wave();   // (own region: the core transform's last LDS reads are done)
-            RL_FOR_LIVE_SLOTS(s) mine[s * LIVE + lane] = S[s];
-        }
-        sync.wg();
-        if (colok) {
-            // slot by slot, a compiler fence in between: left alone the scheduler issues all 4 x NS reads first and holds
-            // 72 registers for them -- enough to make the multi-view modes spill
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (slot_live(s)) {
-                    cx<T> acc = mk<T>((T)0, (T)0);
-#pragma unroll
-                    for (int q = 0; q < M; ++q) acc = acc + times_i_pow(column_lds[q * C * LP + s * LIVE + lane], q * g, inv);
-                    S[s] = acc;
-                }
-                if (s % 3 == 2) sync.wave();
-            }
-        }
-    };
-    // Z <- X * psf_hat[view] on this wave's quarter of the column spectrum (Z may be X)
-    auto multiply_into = [&](const Set& X, Set& Z, int view) {
-        const size_t pcol = ((size_t)view * p.kx + col) * L + (size_t)Li * g;
-        if (colok) {
-            RL_FOR_LIVE_SLOTS(s) {
-                if constexpr (REALP) Z[s] = scale(X[s], p.psf_hat_re[pcol + slot_index(s)]);
-                else Z[s] = cmul(X[s], p.psf_hat[pcol + slot_index(s)]);
-            }
-        }
-    };
-    // X' (this wave's quarter) -> class g of the output image.  Barriers inside: before the exchange overwrites the
-    // region, after it, before the inverse transform overwrites it, before the store.
-    auto inverse_class = [&](Set& Z, cx<T>* __restrict__ out, const cx<T>* tw) {
-        sync.wg();                       // nobody reads this wave's region any more
-        all_to_all(Z, true);
-        if (colok && g > 0) {
-            RL_FOR_LIVE_SLOTS(s) {
-                const cx<T> t = tw[CTW + (g - 1) * Li + slot_index(s)];
-                Z[s] = cmul(Z[s], mk<T>(t.re, -t.im));
-            }
-        }
-        sync.wg();                       // the exchange has been read: the regions are free for the transforms
-        if (colok) {
-            cx<T> v[VMAX];
-#pragma unroll
-            for (int s = 0; s < NV; ++s) v[s] = Z[s];
-            cx<T> tl = mk<T>((T)0, (T)0);
-            if constexpr (FL::TAIL) tl = Z[NV];
-            run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw, sync);
-            sync.wave();   // last pass' LDS reads are done before the column is overwritten
-#pragma unroll
-            for (int nb = 0; nb < IL::NB; ++nb) {
-                const int j = lane + nb * 64;
-                if (j < IL::NBF) {
-#pragma unroll
-                    for (int rr = 0; rr < IL::R; ++rr) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), rr) = v[nb * IL::R + rr];
-                }
-            }
-        }
-        sync.wg();
-        store_class(out);
-    };
-
-    if constexpr (MODE == COL_PER_IMAGE) {
-        const int frame = by / p.V, view = by % p.V;
-        Set Y;
-        forward_class(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img_in, Y, p.tw);
-        all_to_all(Y, false);            // Y = X[k + Li g]
-        multiply_into(Y, Y, view);
-        inverse_class(Y, p.out + (size_t)by * img, p.tw);
-    } else if constexpr (MODE == COL_H_MULTI) {
-        // by = frame: ONE forward transform of the frame's spectrum (H, ref:573-576), V products + inverse transforms
-        Set X, Z;
-        forward_class(p.in + (size_t)by * img_in, X, p.tw);
-        all_to_all(X, false);
-        for (int view = 0; view < p.V; ++view) {
-            const cx<T>* tw = launder(p.tw);
-            multiply_into(X, Z, view);
-            inverse_class(Z, p.out + ((size_t)by * p.V + view) * img, tw);
-        }
-    } else {   // COL_HT_SUM: the V products are summed in the Fourier domain, one inverse transform (see colconv_wave_body)
-        Set Y, A;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) A[s] = mk<T>((T)0, (T)0);
-        for (int view = 0; view < p.V; ++view) {
-            const cx<T>* tw = launder(p.tw);
-            if (view > 0) sync.wg();     // the previous view's exchange has been read
-            forward_class(p.in + ((size_t)by * p.V + view) * img_in, Y, tw);
-            all_to_all(Y, false);
-            multiply_into(Y, Y, view);
-            if (colok) {
-                RL_FOR_LIVE_SLOTS(s) A[s] = A[s] + Y[s];
-            }
-        }
-        inverse_class(A, p.out + (size_t)by * img, p.tw);
-    }
-#undef RL_FOR_LIVE_SLOTS
+// complex elements of one image's column spectra in register-slot order (ColParams::xs_in / xs_out)
+template <class Cfg, int M, int C>
+constexpr size_t outer_slots_tile_elems() {
+    using FL = PassInfo<Cfg, false, Cfg::NP - 1>;
+    return (size_t)(FL::NBM * FL::R + 1) * M * 64 * C;
 }
+
+// (Round 3 also carried colconv_outer4_body -- FOUR waves per column, wave g owning residue class g and the spectrum quarter
+// X[k + Li g], the radix-4 step an all-to-all through LDS, one register set per wave -- for the fused multi-view modes, fed by
+// ratio spectra in a 4 x 4 blocked layout: COL_HT_SUM on it beat V per-image launches by 7-21 %, the split pass above beats it
+// by another 11 % with a third of the code.  Removed with the layout)
 
 // -------------------------------- row pass ---------------------------------
 // Two real image rows (2p, 2p+1) ride through one complex transform of length
@@ -779,7 +630,6 @@ struct RowParams {
     // spectra are computed once per plan and every frame's ROW_RATIO reads them.
     int in_mod = 0;
     int sub_one = 0;        // ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE multiplies by max(1 + acc / norm, 0): see rl_ratio
-    int out_blocked4 = 0;   // rowpass_body: spec_out is written in the 4 x 4 blocked layout (spec_off4; image = spec_rows4(ny) rows)
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
 };
 
@@ -997,16 +847,15 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             }
         }
         fft_sync<Cfg>(sync);
-        const bool blk = p.out_blocked4 != 0;
-        cx<T>* __restrict__ so = p.spec_out + (size_t)by * (blk ? spec_image_elems(spec_rows4(p.ny), p.pitch) : simg);
+        cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg;
         constexpr int NUP = (L / 2 + TT) / TT;
 #pragma unroll
         for (int it = 0; it < NUP; ++it) {
             const int k = t + it * TT;
             if (k <= L / 2) {
                 const cx<T> zk = view_lds.at(k), zm = view_lds.at((L - k) % L);
-                if (ok0) so[blk ? spec_off4(r0, k, p.pitch) : spec_off(r0, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
-                if (ok1) so[blk ? spec_off4(r1, k, p.pitch) : spec_off(r1, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
+                if (ok0) so[spec_off(r0, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
+                if (ok1) so[spec_off(r1, k, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
             }
         }
         rl_stamp(sync, 5);
@@ -1142,20 +991,6 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
         }
     }
     fft_sync<Cfg>(sync);
-    if (p.out_blocked4) {   // (ROW_RATIO of a plan whose column length takes the blocked ratio spectra: spec_off4)
-        cx<T>* __restrict__ so = p.spec_out + (size_t)by * spec_image_elems(spec_rows4(p.ny), p.pitch);
-#pragma unroll
-        for (int it = 0; it < NPK; ++it) {
-            const int kk = tl_ + it * 64;
-            if (kk <= L / 2) {
-                const cx<T> zk = view_lds.at(kk), zm = view_lds.at((L - kk) % L);
-                so[spec_off4(r0, kk, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), p.qscale);
-                if (ok1) so[spec_off4(r0 + 1, kk, p.pitch)] = rl_spec_round(mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)), p.qscale);
-            }
-        }
-        rl_stamp(sync, 5);
-        return;
-    }
     cx<T>* __restrict__ so0 = p.spec_out + (size_t)by * simg + (size_t)r0 * p.pitch;
     cx<T>* __restrict__ so1 = so0 + p.pitch;
 #pragma unroll

@@ -163,8 +163,7 @@ struct OuterCol {
     static constexpr bool value = false;
     using Core = typename CfgFor<64>::Cfg;   // unused
     static constexpr int M = 2, C = 8, MIN_WAVES = 1;
-    static constexpr int FOUR_WAVES = 0;                 // colconv_outer4_body: 1 its multi-view modes, 2 the per-image mode too
-    static constexpr int MULTI_MODES = 0;                // KernelTable::col_multi bits the plan should use
+    static constexpr bool SPLIT = false;                 // the split pass (COL_SPLIT_*) is what multi-view f32 plans run
 };
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
@@ -177,33 +176,31 @@ struct OuterCol {
 #ifndef RL_OUTER_MIN_WAVES
 #define RL_OUTER_MIN_WAVES 4
 #endif
-// The multi-view column modes of the long transforms live in colconv_outer4_body (four waves per column, one register set per
-// wave).  History: on colconv_outer_body they hold two 4 x 10 register sets (256 VGPRs + 81 spilled dwords, one workgroup per CU:
-// round 2, H 0.355 -> 0.478 ms per 4-frame launch); on a two-waves-per-column body (round 3) 128 VGPRs + 60-100 spilled dwords,
-// 991 us against 730 us for the V per-image launches.  Both removed.
-#ifndef RL_OUTER_BLOCKED4
-#define RL_OUTER_BLOCKED4 1        // COL_HT_SUM reads its ratio spectra in the 4 x 4 blocked layout (conv_kernels.hpp spec_off4)
-#endif
-#ifndef RL_OUTER_FOUR_WAVES
-#define RL_OUTER_FOUR_WAVES 1      // 1: colconv_outer4_body for the multi-view modes; 2: for the per-image mode too (measured 40 % slower)
-#endif
-#ifndef RL_OUTER_H_MULTI
-#define RL_OUTER_H_MULTI 0
-#endif
-
+// Multi-view plans on these lengths run the SPLIT pass (conv_kernels.hpp COL_SPLIT_*).  History of the fused multi-view modes
+// here: on colconv_outer_body two 4 x 10 register sets (256 VGPRs + 81 spilled dwords: round 2); on a two-waves-per-column body
+// 128 VGPRs + 60-100 spilled dwords, 991 us against 730 us for V per-image launches; on a four-waves-per-column body with the
+// ratio spectra in a 4 x 4 blocked layout no spill and 205-218 frames/s at 2048^2 x 4 views (V per-image launches: 190) -- the
+// split pass gives 236-244.  All removed.
 template <>
 struct OuterCol<2304> {
     static constexpr bool value = RL_OUTER_2304 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
-    static constexpr int FOUR_WAVES = RL_OUTER_FOUR_WAVES;
-    // Measured at 2048^2, 4 views, 6-frame launches (us, in situ): H as 24 per-image launches of colconv_outer_body 730, as
-    // COL_H_MULTI on four waves 952; H_t per image 730 + ROW_UPDATE over 4 spectra 732, as COL_HT_SUM on four waves 974 +
-    // ROW_UPDATE over one spectrum 179.  So the plan uses the Fourier-domain view sum (bit 1 of KernelTable::col_multi), not the
-    // shared forward transform (bit 0: RL_OUTER_H_MULTI).
-    // bit 3: only from three views on -- at two, V per-image launches + the pre-summed single-transform update (rowpass_body
-    // PRESUM) are faster: 2048^2, 2 views 386 against 370 frames/s; 4 views 195 against 211
-    static constexpr int MULTI_MODES = FOUR_WAVES ? (2 | 8 | (RL_OUTER_H_MULTI ? 1 : 0) | (RL_OUTER_BLOCKED4 ? 4 : 0)) : 0;
+    static constexpr bool SPLIT = true;    // 2048^2: 4 views 215 -> 236-244 frames/s, 2 views 407 -> 414
+};
+// 1152 = 2 x 576 (round 3, for the split pass of multi-view plans; as a whole-pass kernel it measured 1.32 -> 1.14 us alone and
+// no gain in the 1024^2 single-view loop in round 2)
+#ifndef RL_OUTER_1152
+#define RL_OUTER_1152 1
+#endif
+template <>
+struct OuterCol<1152> {
+    static constexpr bool value = RL_OUTER_1152 != 0;
+    using Core = typename CfgFor<576>::Cfg;
+    static constexpr int M = 2, C = 8, MIN_WAVES = 4;
+    // measured at 1024^2 (frames/s; (8,9,16) x 144 workgroup-synchronous kernel / this body per image / its split pass):
+    // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -
+    static constexpr bool SPLIT = false;
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
@@ -216,7 +213,7 @@ struct OuterCol<4608> {
     static constexpr bool value = RL_OUTER_4608 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 8, C = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
-    static constexpr int FOUR_WAVES = 0, MULTI_MODES = 0;
+    static constexpr bool SPLIT = true;    // 4096^2, 4 views: 33.5 -> 45 frames/s
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

@@ -113,31 +113,21 @@ __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_oute
     DevSync s;
     using OC = OuterCol<L>;
     unsigned bx = blockIdx.x, by = blockIdx.y;
-    const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
-    if (total % 8 == 0) {   // XCD-contiguous, image-major work order (speed only)
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gridDim.x * gridDim.y;
+    if (total % 8 == 0) {   // XCD-contiguous work order (speed only)
         const unsigned lin = by * gx + bx;
         const unsigned w = (lin % 8) * (total / 8) + lin / 8;
-        bx = w % gx;
-        by = w / gx;
+        if constexpr (MODE == COL_SPLIT_INV || MODE == COL_SPLIT_INV_SUM) {
+            // tile-major: the images of one column tile (views fastest, then frames) follow each other on one XCD, so the tile's
+            // multipliers (and, COL_SPLIT_INV, the frame's parked spectra its V views share) are fetched once and then hit in L2
+            bx = w / gy;
+            by = w % gy;
+        } else {   // image-major
+            bx = w % gx;
+            by = w / gx;
+        }
     }
     colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
-}
-// four waves per column (conv_kernels.hpp colconv_outer4_body; L = 4 x 576): C = 4 columns, 16 waves per workgroup, one
-// workgroup per CU.  All three column modes, none of them spills.
-template <int L, int C, bool REALP, int MODE = COL_PER_IMAGE>
-__global__ void __launch_bounds__(256 * C, 4) k_colconv_outer4(const ColParams<float> p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    DevSync s;
-    using OC = OuterCol<L>;
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-    const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
-    if (total % 8 == 0) {   // XCD-contiguous, image-major work order (speed only)
-        const unsigned lin = by * gx + bx;
-        const unsigned w = (lin % 8) * (total / 8) + lin / 8;
-        bx = w % gx;
-        by = w / gx;
-    }
-    colconv_outer4_body<typename OC::Core, C, float, REALP, MODE>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
 }
 template <int L>
 static void fill_outer_twiddles(double* out) {
@@ -282,26 +272,19 @@ static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigne
             const ColParams<float>& p = *static_cast<const ColParams<float>*>(params);
             constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
             const dim3 grid((unsigned)((p.kx + OC::C - 1) / OC::C), gy), block(64 * OC::C);
-            if constexpr (OC::FOUR_WAVES) {   // four waves per column: the multi-view modes, and -- OC::FOUR_WAVES > 1 -- the per-image mode too
-                constexpr int C4 = 4;
-                constexpr size_t lds4 = (size_t)4 * C4 * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
-                const dim3 grid4((unsigned)((p.kx + C4 - 1) / C4), gy), block4(256 * C4);
-                if (p.mode == COL_H_MULTI) {
-                    if (p.psf_hat_re) rl_launch(k_colconv_outer4<RL_CFG_L, C4, true, COL_H_MULTI>, grid4, block4, lds4, s, p);
-                    else rl_launch(k_colconv_outer4<RL_CFG_L, C4, false, COL_H_MULTI>, grid4, block4, lds4, s, p);
-                    return hipGetLastError();
-                }
-                if (p.mode == COL_HT_SUM) {
-                    if (p.psf_hat_re) rl_launch(k_colconv_outer4<RL_CFG_L, C4, true, COL_HT_SUM>, grid4, block4, lds4, s, p);
-                    else rl_launch(k_colconv_outer4<RL_CFG_L, C4, false, COL_HT_SUM>, grid4, block4, lds4, s, p);
-                    return hipGetLastError();
-                }
-                if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
-                if constexpr (OC::FOUR_WAVES > 1) {
-                    if (p.psf_hat_re) rl_launch(k_colconv_outer4<RL_CFG_L, C4, true>, grid4, block4, lds4, s, p);
-                    else rl_launch(k_colconv_outer4<RL_CFG_L, C4, false>, grid4, block4, lds4, s, p);
-                    return hipGetLastError();
-                }
+            if (p.mode == COL_SPLIT_FWD) {
+                rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, grid, block, lds, s, p);
+                return hipGetLastError();
+            }
+            if (p.mode == COL_SPLIT_INV) {
+                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, grid, block, lds, s, p);
+                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, grid, block, lds, s, p);
+                return hipGetLastError();
+            }
+            if (p.mode == COL_SPLIT_INV_SUM) {
+                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, grid, block, lds, s, p);
+                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, grid, block, lds, s, p);
+                return hipGetLastError();
             }
             if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
             if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds, s, p);
@@ -370,15 +353,11 @@ static hipError_t prepare() {
         constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds)) != hipSuccess) return e;
-        if constexpr (OC::FOUR_WAVES) {
-            constexpr size_t lds4 = (size_t)16 * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
-            if ((e = allow_lds(k_colconv_outer4<RL_CFG_L, 4, true>, lds4)) != hipSuccess) return e;
-            if ((e = allow_lds(k_colconv_outer4<RL_CFG_L, 4, false>, lds4)) != hipSuccess) return e;
-            if ((e = allow_lds(k_colconv_outer4<RL_CFG_L, 4, true, COL_H_MULTI>, lds4)) != hipSuccess) return e;
-            if ((e = allow_lds(k_colconv_outer4<RL_CFG_L, 4, false, COL_H_MULTI>, lds4)) != hipSuccess) return e;
-            if ((e = allow_lds(k_colconv_outer4<RL_CFG_L, 4, true, COL_HT_SUM>, lds4)) != hipSuccess) return e;
-            if ((e = allow_lds(k_colconv_outer4<RL_CFG_L, 4, false, COL_HT_SUM>, lds4)) != hipSuccess) return e;
-        }
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, lds)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, lds)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, lds)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, lds)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, lds)) != hipSuccess) return e;
     }
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
@@ -391,23 +370,25 @@ template <int L, bool OUTER>
 struct OuterTw {   // column twiddle table of the f32 kernel: the outer-decimation kernel's, where the length has one
     static constexpr int count = PassTw<typename ColCfgFor<L>::type, false, 0>::TOTAL;
     static void fill(double* out) { fill_pass_twiddles<typename ColCfgFor<L>::type>(out); }
+    static constexpr size_t split_tile = 0;
 };
 template <int L>
 struct OuterTw<L, true> {
     using OC = OuterCol<L>;
     static constexpr int count = PassTw<typename OC::Core, false, 0>::TOTAL + (OC::M - 1) * OC::Core::L;
     static void fill(double* out) { fill_outer_twiddles<L>(out); }
+    static constexpr size_t split_tile = OC::SPLIT ? outer_slots_tile_elems<typename OC::Core, OC::M, OC::C>() : 0;
 };
 
 const KernelTable* RL_TABLE_FN() {
     constexpr bool OUTER = OuterCol<RL_CFG_L>::value;
     constexpr int WP = WavePrivate<CCfg>::value ? 1 : 0;
     static const KernelTable t = {Cfg::L, Cfg::T, {OUTER ? OuterCol<RL_CFG_L>::C : kC32, kC64}, {kQ32, kQ64},
-                                  {OUTER ? 1 : WP, WP}, {OUTER ? OuterCol<RL_CFG_L>::MULTI_MODES : 3 * WP, 3 * WP},
+                                  {OUTER ? 1 : WP, WP}, {OUTER ? 0 : 3 * WP, 3 * WP},
                                   PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
                                   {OuterTw<RL_CFG_L, OUTER>::count, PassTw<CCfg, false, 0>::TOTAL},
                                   {OuterTw<RL_CFG_L, OUTER>::fill, fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,
-                                  kPairRows ? launch_row_pair : nullptr};
+                                  kPairRows ? launch_row_pair : nullptr, OuterTw<RL_CFG_L, OUTER>::split_tile};
     return &t;
 }
 

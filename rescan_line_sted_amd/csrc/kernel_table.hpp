@@ -22,9 +22,7 @@ struct KernelTable {
     int Q[2];         // row pairs per workgroup in the row kernels, per dtype
     // per dtype (the f32 and f64 column kernels of a length may be different kernels):
     int psf_transposed[2];   // column kernel reads psf_hat as [view][Kx][L] (one wave per column)
-    int col_multi[2];        // multi-view column modes the plan should use: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM,
-                             // bit 2 COL_HT_SUM wants its input in the 4 x 4 blocked layout (ColParams::in_blocked4),
-                             // bit 3 COL_HT_SUM only for three views or more
+    int col_multi[2];        // fused multi-view column modes the plan should use: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM
     int tw_count;         // complex entries of the per-pass twiddle table (fft_core.hpp PassTw), row kernels
     void (*fill_tw)(double* out);   // host: writes 2*tw_count doubles (re, im interleaved)
     int tw_count_col[2];  // the same for the column kernels (their geometry may differ: fft_configs.hpp ColCfgFor)
@@ -38,6 +36,10 @@ struct KernelTable {
     // ROW_FWD / ROW_RATIO / ROW_UPDATE, one view): grid (ceil(ny / Q), pairs), RowParams::frames = frames covered.
     // nullptr when the length's row transform is not wave private.
     hipError_t (*launch_row_pair)(int dtype, int mode, const void* params, unsigned grid_y_pairs, hipStream_t s);
+    // The split column pass of the long f32 transforms (conv_kernels.hpp COL_SPLIT_FWD / COL_SPLIT_INV / COL_SPLIT_INV_SUM through
+    // launch_col): complex elements of one C-column tile's spectra in register-slot order -- an image's parked spectra take
+    // ceil(kx / C[0]) * split_tile_elems -- or 0 where the length has no such kernels.
+    size_t split_tile_elems;
 };
 
 const KernelTable* table_64();

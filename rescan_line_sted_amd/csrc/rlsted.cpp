@@ -76,7 +76,7 @@ struct rl_deconv {
     double psf_hat_imag_ratio = 0;   // max |im| / max |z| of the PSF spectrum
     void* spec_a = nullptr;    // [B] spectrum images (layout: conv_kernels.hpp spec_off)
     void* spec_b = nullptr;    // [B*V] spectrum images
-    void* spec_c = nullptr;    // [B*V] ratio spectra in the 4 x 4 blocked layout (blocked4() plans only)
+    void* spec_x = nullptr;    // [B*V] column spectra in register-slot order between the halves of the split column pass (col_split() plans)
     void* spec_ones = nullptr; // [V] column-transformed spectra of H(estimate = 1): the same for every frame (ref:522)
     // storage-precision study builds (conv_kernels.hpp RL_SPEC_QUANT): powers of two that bring the DC term of an
     // estimate-type / ratio-type spectrum to 2^14 (RLSTED_Q_EXP_EST / RLSTED_Q_EXP_RATIO = log2 of the DC bound)
@@ -291,7 +291,7 @@ struct rl_deconv {
     // ---- in-situ kernel timing (rl_deconv_time_cycle): an event pair around every launch of one whole
     // cycle, on the stream the launch goes to, with the slice streams overlapping as in production
     enum TimedKind { TK_COL_H = 0, TK_RATIO, TK_COL_HT, TK_UPDATE, TK_FWD, TK_INV, TK_POISSON, TK_COUNT };
-    struct TimedLaunch { int kind; hipEvent_t a, b; };
+    struct TimedLaunch { int kind; hipEvent_t a, b; bool cont; };   // cont: second launch of one pass (its time adds to the pass)
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -308,8 +308,8 @@ struct rl_deconv {
     // rl_launch, which stamps the kernel's own begin / end on the events (what a kernel trace shows);
     // otherwise the events are recorded on the stream around the launch(es).
     struct TimedScope {
-        rl_deconv* h; hipEvent_t a = nullptr, b = nullptr; int kind; bool ext;
-        TimedScope(rl_deconv* h_, int kind_, bool ext_ = true) : h(h_), kind(kind_), ext(ext_) {
+        rl_deconv* h; hipEvent_t a = nullptr, b = nullptr; int kind; bool ext; bool cont = false;
+        TimedScope(rl_deconv* h_, int kind_, bool ext_ = true, bool cont_ = false) : h(h_), kind(kind_), ext(ext_), cont(cont_) {
             if (!h->timing || !(a = h->pool_event()) || !(b = h->pool_event())) return;
             if (ext) {
                 launch_timing().start = a;
@@ -327,7 +327,7 @@ struct rl_deconv {
             } else {
                 (void)hipEventRecord(b, h->cur());
             }
-            h->timed.push_back({kind, a, b});
+            h->timed.push_back({kind, a, b, cont});
         }
     };
 
@@ -336,12 +336,59 @@ struct rl_deconv {
 
     bool col_multi = true;   // RLSTED_COL_MULTI=0 (A/B knob): V per-image column launches even where the multi-view modes exist
     // KernelTable::col_multi: bit 0 COL_H_MULTI, bit 1 COL_HT_SUM.  wave_private_y(): the Fourier-domain view sum exists (and is wanted)
-    bool wave_private_y() const { return col_multi && (ty->col_multi[dtype] & 2) != 0 && (V >= 3 || !(ty->col_multi[dtype] & 8)); }
+    bool wave_private_y() const { return col_multi && (ty->col_multi[dtype] & 2) != 0; }
     bool h_multi() const { return col_multi && (ty->col_multi[dtype] & 1) != 0; }
-    // ROW_RATIO writes the ratio spectra into spec_c in the 4 x 4 blocked layout, COL_HT_SUM reads them there (RLSTED_BLOCKED4=0: A/B knob)
-    bool blocked4_wanted = true;
-    bool blocked4() const { return blocked4_wanted && V > 1 && fuse_views && wave_private_y() && (ty->col_multi[dtype] & 4) != 0; }
-    size_t n_spec4() const { return spec_image_elems(spec_rows4(ny), pitch); }
+    // The split column pass (conv_kernels.hpp COL_SPLIT_*; f32 multi-view plans on the long column transforms): H transforms a frame's
+    // spectrum once for its V views, H_t sums the views' products before one inverse transform (RLSTED_COL_SPLIT=0: A/B knob)
+    bool split_wanted = true;
+    bool col_split() const { return split_wanted && dtype == RL_F32 && V > 1 && ty->split_tile_elems > 0; }
+    size_t n_spec_x() const { return (size_t)((kx + ty->C[RL_F32] - 1) / ty->C[RL_F32]) * ty->split_tile_elems; }
+    // one half of the split pass over `images` launch rows
+    int col_split_launch(int mode, const void* in, void* out, const void* xs_in, void* xs_out, int images, int in_sb, int in_sv, ColKind kind,
+                         bool cont) {
+        ColParams<float> p;
+        p.in = (const cx<float>*)in;
+        p.out = (cx<float>*)out;
+        p.xs_in = (const cx<float>*)xs_in;
+        p.xs_out = (cx<float>*)xs_out;
+        p.psf_hat = (const cx<float>*)psf_hat;
+        p.psf_hat_re = (const float*)psf_hat_re;
+        p.qscale = kind == COL_H ? q_est : q_ratio;
+        p.tw = (const cx<float>*)twy;
+        p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V;
+        p.mode = mode;
+        p.in_sb = in_sb; p.in_sv = in_sv;
+        p.images = images;
+        p.order = 1;
+        const int C = ty->C[dtype];
+        {
+            TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT, true, cont);
+            HIP_TRY(ty->launch_col(dtype, &p, (unsigned)((kx + C - 1) / C), (unsigned)images, cur()));
+        }
+        if (rl::debug_sync()) {
+            hipError_t e = hipStreamSynchronize(cur());
+            if (e != hipSuccess) return fail(RL_ERR_HIP, "split column kernel mode " + std::to_string(mode) + ": " + hipGetErrorString(e));
+        }
+        return RL_OK;
+    }
+    // kind COL_H: `in` = the frames' spectra -> out = frames * V images; COL_HT_FUSED: in = frames * V images -> out = frames
+    // xs: this slice's part of spec_x (frames * V images of n_spec_x() elements)
+    int col_split_pass(const void* in, void* out, void* xs, int frames, ColKind kind) {
+        const size_t sp = n_spec() * 2 * sizeof(float), sx = n_spec_x() * 2 * sizeof(float);
+        const int step = std::max(1, kMaxGridY / V);
+        for (int f0 = 0; f0 < frames; f0 += step) {
+            const int nf = std::min(step, frames - f0);
+            void* x = (char*)xs + (size_t)f0 * V * sx;
+            if (kind == COL_H) {
+                RL_TRY(col_split_launch(COL_SPLIT_FWD, (const char*)in + (size_t)f0 * sp, nullptr, nullptr, x, nf, 1, 0, kind, false));
+                RL_TRY(col_split_launch(COL_SPLIT_INV, nullptr, (char*)out + (size_t)f0 * V * sp, x, nullptr, nf * V, 1, 0, kind, true));
+            } else {
+                RL_TRY(col_split_launch(COL_SPLIT_FWD, (const char*)in + (size_t)f0 * V * sp, nullptr, nullptr, x, nf * V, 1, 0, kind, false));
+                RL_TRY(col_split_launch(COL_SPLIT_INV_SUM, nullptr, (char*)out + (size_t)f0 * sp, x, nullptr, nf, 1, 0, kind, true));
+            }
+        }
+        return RL_OK;
+    }
     bool psf_transposed() const { return ty->psf_transposed[dtype] != 0; }   // psf_hat is [view][Kx][Ly]
     template <typename T>
     int col_t(const void* in, void* out, int frames, ColKind kind) {
@@ -362,7 +409,6 @@ struct rl_deconv {
             gy = (unsigned)frames;
         } else if (V > 1 && kind == COL_HT_FUSED && wave_private_y()) {
             p.mode = COL_HT_SUM;
-            p.in_blocked4 = blocked4() ? 1 : 0;
             gy = (unsigned)frames;
         } else if (kind == COL_HT_FUSED && V > 1) {
             return fail(RL_ERR_STATE, "internal: fused H_t needs a wave-private column transform");
@@ -388,12 +434,11 @@ struct rl_deconv {
     static constexpr int kMaxGridY = 65535;
     int col(const void* in, void* out, int frames, ColKind kind) {
         const size_t sp = n_spec() * 2 * esize(dtype);   // bytes of one spectrum image
-        const size_t sp_in = kind == COL_HT_FUSED && blocked4() ? n_spec4() * 2 * esize(dtype) : sp;
         const size_t in_per = kind == COL_H ? 1 : (size_t)V, out_per = kind == COL_HT_FUSED ? 1 : (size_t)V;
         const int step = std::max(1, kMaxGridY / V);
         for (int f0 = 0; f0 < frames; f0 += step) {
             const int nf = std::min(step, frames - f0);
-            const void* i = (const char*)in + (size_t)f0 * in_per * sp_in;
+            const void* i = (const char*)in + (size_t)f0 * in_per * sp;
             void* o = (char*)out + (size_t)f0 * out_per * sp;
             RL_TRY(dtype == RL_F32 ? col_t<float>(i, o, nf, kind) : col_t<double>(i, o, nf, kind));
         }
@@ -402,10 +447,9 @@ struct rl_deconv {
     int col(const void* in, void* out, int frames, bool h_mode) { return col(in, out, frames, h_mode ? COL_H : COL_HT_VIEW); }
     template <typename T>
     int row_t(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-              const void* scale, int views, int in_mod = 0, bool out_blocked = false) {
+              const void* scale, int views, int in_mod = 0) {
         RowParams<T> p;
         p.in_mod = in_mod;
-        p.out_blocked4 = out_blocked ? 1 : 0;
         p.sub_one = sub_one ? 1 : 0;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
@@ -433,10 +477,9 @@ struct rl_deconv {
         return RL_OK;
     }
     int row(int mode, unsigned gy, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm,
-            const void* scale = nullptr, int views = -1, int in_mod = 0, bool out_blocked = false) {
+            const void* scale = nullptr, int views = -1, int in_mod = 0) {
         if (views < 0) views = V;
         const size_t sp = n_spec() * 2 * esize(dtype), im = n_img() * esize(dtype);
-        const size_t sp_out = (out_blocked ? n_spec4() : n_spec()) * 2 * esize(dtype);
         const bool multi = mode == ROW_UPDATE || mode == ROW_ADJ;   // `views` input spectra per image
         const unsigned piece = in_mod > 0 ? (unsigned)(kMaxGridY / in_mod * in_mod) : (unsigned)kMaxGridY;
         for (unsigned g0 = 0; g0 < gy; g0 += piece) {
@@ -444,12 +487,12 @@ struct rl_deconv {
             // (kMaxGridY is a multiple of every in_mod in use only by accident: a shared input is not moved on,
             // and the image index restarts at 0 in each piece -- so pieces must start on a multiple of in_mod)
             const void* si = spec_in ? (const char*)spec_in + (in_mod > 0 ? 0 : (size_t)g0 * (multi ? (size_t)views : 1) * sp) : nullptr;
-            void* so = spec_out ? (char*)spec_out + (size_t)g0 * sp_out : nullptr;
+            void* so = spec_out ? (char*)spec_out + (size_t)g0 * sp : nullptr;
             const void* sr = src ? (const char*)src + (size_t)g0 * im : nullptr;
             void* ds = dst ? (char*)dst + (size_t)g0 * im : nullptr;
             const void* sc = scale ? (const char*)scale + (size_t)g0 * esize(dtype) : nullptr;
-            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod, out_blocked)
-                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod, out_blocked));
+            RL_TRY(dtype == RL_F32 ? row_t<float>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod)
+                                   : row_t<double>(mode, ng, si, so, sr, ds, nrm, sc, views, in_mod));
         }
         return RL_OK;
     }
@@ -607,19 +650,33 @@ struct rl_deconv {
             RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
             return RL_OK;
         }
-        // (blocked4(): the ratio spectra go to spec_c in the layout COL_HT_SUM's four-column tiles read whole lines of -- not in
-        // place, a row pair's 4 x 4 blocks hold rows other workgroups have yet to read)
-        const bool blk = blocked4();
-        void* sr = blk ? off(spec_c, (size_t)f0 * V * n_spec4() * 2) : sb;
+        if (col_split()) {
+            // the split column pass: 1 + V and V + 1 column transforms per frame instead of 2 V and (fused) V + 1 on one register set
+            void* sx = off(spec_x, (size_t)f0 * V * n_spec_x() * 2);
+            if (first) {
+                RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V));
+            } else {
+                RL_TRY(col_split_pass(sa, sb, sx, nf, COL_H));
+                RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));
+            }
+            if (fuse_views) {
+                RL_TRY(col_split_pass(sb, sa, sx, nf, COL_HT_FUSED));
+                RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm, nullptr, 1));
+            } else {
+                RL_TRY(col(sb, sb, nf, false));
+                RL_TRY(row(ROW_UPDATE, (unsigned)nf, sb, sa, nullptr, off(est, (size_t)f0 * n_img()), norm));
+            }
+            return RL_OK;
+        }
         if (first) {
-            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sr, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V, blk));
+            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V));
         } else {
             RL_TRY(col(sa, sb, nf, true));                                                                   // H(est), column part
-            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sr, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, 0, blk));   // meas / H(est)
+            RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));   // meas / H(est)
         }
         if (fuse_views && V > 1 && wave_private_y()) {
             // views summed in the Fourier domain: one inverse column + one inverse row transform per frame
-            RL_TRY(col(sr, sa, nf, COL_HT_FUSED));
+            RL_TRY(col(sb, sa, nf, COL_HT_FUSED));
             RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm, nullptr, 1));
         } else {
             RL_TRY(col(sb, sb, nf, false));                                                                  // H_t, column part
@@ -825,7 +882,7 @@ int rl_deconv_destroy(rl_deconv* h) {
     hipStreamSynchronize(h->ctx->stream);
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
         if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
-    void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->spec_c, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
+    void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->spec_x, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -869,11 +926,11 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         {&h->noiseless, B * V * h->n_img() * es},     {&h->meas, B * V * h->n_img() * es},
         {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
         {&h->scratch, std::max(B * V * h->n_img() * es, aux_poisson_workspace_bytes(B * V * h->n_img()))}};   // also the Poisson work list
-    if (h->blocked4()) {   // (rows 4 * (ny / 4) .. of the last block row are never written when ny % 4 != 0 -- and never read)
-        const size_t n = B * V * h->n_spec4() * 2 * es;
-        HIP_TRY(hipMalloc(&h->spec_c, n + RL_STREAM_SLACK));
-        HIP_TRY(hipMemsetAsync(h->spec_c, 0, n + RL_STREAM_SLACK, ctx->stream));
-        h->bytes += n + RL_STREAM_SLACK;
+    if (h->col_split()) {
+        const size_t n = B * V * h->n_spec_x() * 2 * es;
+        HIP_TRY(hipMalloc(&h->spec_x, n));
+        HIP_TRY(hipMemsetAsync(h->spec_x, 0, n, ctx->stream));
+        h->bytes += n;
     }
     for (const Req& r : reqs) {
         // RL_STREAM_SLACK: the streaming row kernels load whole 64-lane segments without clamping;
@@ -1124,7 +1181,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
         if (h->lanes < 1) h->lanes = 1;
         if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
     }
-    if (getenv("RLSTED_BLOCKED4")) h->blocked4_wanted = atoi(getenv("RLSTED_BLOCKED4")) != 0;
+    if (getenv("RLSTED_COL_SPLIT")) h->split_wanted = atoi(getenv("RLSTED_COL_SPLIT")) != 0;
     if (getenv("RLSTED_COL_MULTI")) h->col_multi = atoi(getenv("RLSTED_COL_MULTI")) != 0;
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     h->exact_norm = getenv("RLSTED_EXACT_NORM") ? atoi(getenv("RLSTED_EXACT_NORM")) != 0 : (dtype == RL_F32);
@@ -1454,7 +1511,7 @@ int rl_deconv_time_cycle(rl_deconv* h, int k, int rng_kind, uint64_t seed, doubl
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
         sum[t.kind] += ms;
-        cnt[t.kind] += 1;
+        if (!t.cont) cnt[t.kind] += 1;
     }
     for (int i = 0; i < rl_deconv::TK_COUNT; ++i) {
         avg_ms[i] = cnt[i] > 0 ? sum[i] / cnt[i] : 0.0;
@@ -1484,20 +1541,23 @@ int rl_deconv_time_kernels(rl_deconv* h, int reps, double* avg_ms) {
         for (int r = 0; r < reps; ++r) {
             const bool one_buffer = h->V == 1 && h->inplace;   // as iterate_chunk(): everything in spec_a
             switch (which) {
-                case 0: RL_TRY(h->col(h->spec_a, one_buffer ? h->spec_a : h->spec_b, nf, true)); break;
+                case 0:
+                    if (h->col_split()) RL_TRY(h->col_split_pass(h->spec_a, h->spec_b, h->spec_x, nf, rl_deconv::COL_H));
+                    else RL_TRY(h->col(h->spec_a, one_buffer ? h->spec_a : h->spec_b, nf, true));
+                    break;
                 case 1:
                     if (one_buffer) RL_TRY(h->row(ROW_RATIO, (unsigned)nf, h->spec_a, h->spec_a, h->meas, nullptr, nullptr));
-                    else RL_TRY(h->row(ROW_RATIO, (unsigned)(nf * h->V), h->spec_b, h->blocked4() ? h->spec_c : h->spec_b, h->meas, nullptr, nullptr,
-                                       nullptr, -1, 0, h->blocked4()));
+                    else RL_TRY(h->row(ROW_RATIO, (unsigned)(nf * h->V), h->spec_b, h->spec_b, h->meas, nullptr, nullptr));
                     break;
                 case 2:   // as iterate_chunk(): in place, fused (Fourier-domain view sum) or per view
                     if (one_buffer) RL_TRY(h->col(h->spec_a, h->spec_a, nf, false));
-                    else if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->blocked4() ? h->spec_c : h->spec_b, h->spec_a, nf, rl_deconv::COL_HT_FUSED));
+                    else if (h->col_split() && h->fuse_views) RL_TRY(h->col_split_pass(h->spec_b, h->spec_a, h->spec_x, nf, rl_deconv::COL_HT_FUSED));
+                    else if (h->fuse_views && h->V > 1 && h->wave_private_y()) RL_TRY(h->col(h->spec_b, h->spec_a, nf, rl_deconv::COL_HT_FUSED));
                     else RL_TRY(h->col(h->spec_b, h->spec_b, nf, false));
                     break;
                 case 3:
                     if (one_buffer) RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_a, h->spec_a, nullptr, h->est, h->norm));
-                    else if (h->fuse_views && h->V > 1 && h->wave_private_y())
+                    else if (h->fuse_views && h->V > 1 && (h->wave_private_y() || h->col_split()))
                         RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_a, h->spec_a, nullptr, h->est, h->norm, nullptr, 1));
                     else RL_TRY(h->row(ROW_UPDATE, (unsigned)nf, h->spec_b, h->spec_a, nullptr, h->est, h->norm));
                     break;

@@ -144,8 +144,6 @@ static int row_m(const RowParams<T>& p, int gy) {
 // RowParams::sub_one of every row launch (conv_kernels.hpp rl_ratio: ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE
 // multiplies by max(1 + acc / norm, 0))
 static int g_sub_one = 0;
-// RowParams::out_blocked4 of every row launch / ColParams::in_blocked4 of every four-wave column launch (conv_kernels.hpp spec_off4)
-static int g_blocked4 = 0;
 
 template <int L, typename T>
 static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, const T* scale,
@@ -153,7 +151,6 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
     auto tw = twiddles<L, T>();
     RowParams<T> p;
     p.sub_one = g_sub_one;
-    p.out_blocked4 = g_blocked4;
     p.spec_in = reinterpret_cast<const cx<T>*>(spec_in);
     p.spec_out = reinterpret_cast<cx<T>*>(spec_out);
     p.src = src; p.dst = dst; p.norm = norm; p.scale = scale; p.tw = tw.data();
@@ -180,7 +177,6 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
 extern "C" {
 
 void emu_set_sub_one(int on) { g_sub_one = on; }
-void emu_set_blocked4(int on) { g_blocked4 = on; }
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
@@ -246,11 +242,10 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
              });
     return 0;
 }
-// colconv_outer4_body: four waves per column (L = 4 * Li), C columns per workgroup
-template <class Core, int C, typename T, int WAVES = 4>
-static int col_outer4_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
-                        int in_sb, int in_sv, int mode) {
-    constexpr int M = 4, L = M * Core::L;
+template <class Core, int M, typename T>
+static int col_outer_split_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
+                       int sum_views) {
+    constexpr int C = 8, L = M * Core::L;
     constexpr int n_core = PassTw<Core, false, 0>::TOTAL;
     std::vector<double> h(2 * (size_t)(n_core + (M - 1) * Core::L));
     fill_pass_twiddles<Core>(h.data());
@@ -268,27 +263,33 @@ static int col_outer4_t(const T* in, T* out, const T* psf_hat, int real_psf, int
     p.psf_hat = real_psf ? nullptr : reinterpret_cast<const cx<T>*>(psf_hat);
     p.psf_hat_re = real_psf ? psf_hat : nullptr;
     p.tw = tw.data();
-    p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
-    p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
-    p.in_blocked4 = g_blocked4;
-    if constexpr (WAVES == 4) {
-        run_grid((kx + C - 1) / C, p.images, 256 * C, (size_t)4 * C * LdsSlots<Core>::value * sizeof(cx<T>),
-                 [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
-                     cx<T>* l = reinterpret_cast<cx<T>*>(lds);
-                     if (mode == COL_H_MULTI) {
-                         if (real_psf) colconv_outer4_body<Core, C, T, true, COL_H_MULTI>(p, tid, bx, by, l, s);
-                         else colconv_outer4_body<Core, C, T, false, COL_H_MULTI>(p, tid, bx, by, l, s);
-                     } else if (mode == COL_HT_SUM) {
-                         if (real_psf) colconv_outer4_body<Core, C, T, true, COL_HT_SUM>(p, tid, bx, by, l, s);
-                         else colconv_outer4_body<Core, C, T, false, COL_HT_SUM>(p, tid, bx, by, l, s);
-                     } else {
-                         if (real_psf) colconv_outer4_body<Core, C, T, true>(p, tid, bx, by, l, s);
-                         else colconv_outer4_body<Core, C, T, false>(p, tid, bx, by, l, s);
-                     }
-                 });
-        return 0;
-    }
-    return -2;
+    // The split pass as the plan runs it.  sum_views = 0 (H): COL_SPLIT_FWD over the `frames` input images, COL_SPLIT_INV per
+    // (frame, view) -> frames * V output images.  sum_views = 1 (H_t): COL_SPLIT_FWD over the frames * V input images,
+    // COL_SPLIT_INV_SUM per frame -> `frames` output images.  The slot-order spectra are poisoned with NaN first.
+    const int n_in = sum_views ? frames * V : frames;
+    const size_t xs_img = (size_t)((kx + C - 1) / C) * outer_slots_tile_elems<Core, M, C>();
+    std::vector<cx<T>> xs((size_t)n_in * xs_img, mk<T>((T)NAN, (T)NAN));
+    p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = 1; p.in_sv = 0; p.order = 1;
+    p.xs_out = xs.data();
+    p.xs_in = xs.data();
+    p.mode = COL_SPLIT_FWD; p.images = n_in;
+    run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
+             [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                 colconv_outer_body<Core, M, C, T, false, COL_SPLIT_FWD>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+             });
+    p.mode = sum_views ? COL_SPLIT_INV_SUM : COL_SPLIT_INV; p.images = sum_views ? frames : frames * V;
+    run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
+             [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                 cx<T>* l = reinterpret_cast<cx<T>*>(lds);
+                 if (sum_views) {
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_SPLIT_INV_SUM>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_SPLIT_INV_SUM>(p, tid, bx, by, l, s);
+                 } else {
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_SPLIT_INV>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_SPLIT_INV>(p, tid, bx, by, l, s);
+                 }
+             });
+    return 0;
 }
 template <int L, typename T>
 static int row_pair_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, const T* norm, int ny, int nx, int frames, int in_mod) {
@@ -339,17 +340,17 @@ int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double
     if (Li == 576 && M == 8) return col_outer_t<C576, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     return -2;
 }
-// colconv_outer4_body (four waves per column, L = 4 * Li): mode 0 = COL_PER_IMAGE (in [frames] or [frames*V] by in_sb / in_sv,
-// out [frames*V]), 1 = COL_H_MULTI, 2 = COL_HT_SUM; C = columns per workgroup: 1, 2 (fast) or 4 (the device's 1024 threads)
-int emu_col_outer4_f64(int Li, int C, int mode, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
-                       int pitch, int V, int frames, int in_sb, int in_sv) {
+// the split column pass (COL_SPLIT_FWD then COL_SPLIT_INV / COL_SPLIT_INV_SUM); sum_views: 0 = H (in [frames], out [frames * V]),
+// 1 = H_t with the views summed (in [frames * V], out [frames])
+int emu_col_outer_split_f64(int Li, int M, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
+                            int pitch, int V, int frames, int sum_views) {
     using C256 = CfgFor<256>::Cfg;
     using C576 = CfgFor<576>::Cfg;
-    if (mode != COL_PER_IMAGE && mode != COL_H_MULTI && mode != COL_HT_SUM) return -2;
-    if (Li == 256 && C == 1) return col_outer4_t<C256, 1, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
-    if (Li == 256 && C == 2) return col_outer4_t<C256, 2, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
-    if (Li == 576 && C == 1) return col_outer4_t<C576, 1, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
-    if (Li == 256 && C == 4) return col_outer4_t<C256, 4, double, 4>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv, mode);
+    if (Li == 256 && M == 4) return col_outer_split_t<C256, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, sum_views);
+    if (Li == 256 && M == 2) return col_outer_split_t<C256, 2, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, sum_views);
+    if (Li == 576 && M == 4) return col_outer_split_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, sum_views);
+    if (Li == 256 && M == 8) return col_outer_split_t<C256, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, sum_views);
+    if (Li == 576 && M == 8) return col_outer_split_t<C576, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, sum_views);
     return -2;
 }
 

@@ -378,102 +378,36 @@ def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
             assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
 
 
-@pytest.mark.parametrize('Li,C,mode,ny,kx,real_psf', [(256, 1, 0, 901, 2, 0), (256, 2, 0, 1024, 3, 1), (576, 1, 0, 2048, 2, 1),
-                                                      (256, 2, 1, 900, 2, 0), (256, 1, 2, 603, 2, 1), (576, 1, 1, 2040, 1, 1),
-                                                      (576, 1, 2, 2048, 1, 0), (256, 4, 0, 1000, 5, 0)])
-def test_outer_decimation_four_waves_per_column(emu, Li, C, mode, ny, kx, real_psf):
-    """colconv_outer4_body (round 3): L = 4 * Li with FOUR waves per column -- wave g transforms residue class g and owns
-    the spectrum quarter X[k + Li g]; the radix-4 step is an all-to-all among the column's waves through LDS.  All three
-    modes against numpy; ragged heights, partial column tiles, real and complex multipliers."""
-    L, V, frames = 4 * Li, 3, 2
+@pytest.mark.parametrize('Li,M,ny,kx,real_psf,sum_views', [(256, 4, 900, 11, 0, 0), (256, 4, 901, 9, 1, 1), (576, 4, 2048, 9, 1, 1),
+                                                             (576, 4, 2001, 3, 0, 0), (256, 8, 1900, 5, 1, 1), (256, 2, 437, 8, 0, 1)])
+def test_split_column_pass(emu, Li, M, ny, kx, real_psf, sum_views):
+    """The SPLIT column pass of colconv_outer_body (round 3): COL_SPLIT_FWD parks the column spectra in register-slot order,
+    COL_SPLIT_INV multiplies one view's in and transforms back (H: the frame's spectrum is transformed once for its V views),
+    COL_SPLIT_INV_SUM sums the V views' products first (H_t: one inverse transform per frame).  Against numpy; the parked
+    spectra start as NaN, so every slot that is read was written."""
+    L, V, frames = M * Li, 3, 2
     pitch = (kx + 7) // 8 * 8
-    rng = np.random.default_rng(Li + mode + ny + C)
-    n_in = frames if mode in (0, 1) else frames * V
-    n_out = frames if mode == 2 else frames * V
+    rng = np.random.default_rng(Li + M + ny + sum_views)
+    n_in = frames * V if sum_views else frames
+    n_out = frames if sum_views else frames * V
     x = np.zeros((n_in, ny, pitch), dtype=np.complex128)
     x[:, :, :kx] = rng.standard_normal((n_in, ny, kx)) + 1j * rng.standard_normal((n_in, ny, kx))
     ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
     out = np.full((n_out, ny, pitch), np.nan + 0j, dtype=np.complex128)
     psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
-    rc = emu.emu_col_outer4_f64(Li, C, mode, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, 1, 0)
+    rc = emu.emu_col_outer_split_f64(Li, M, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, sum_views)
     assert rc == 0
     full = np.zeros((n_in, L, kx), dtype=np.complex128)
     full[:, :ny] = x[:, :, :kx]
     spec = np.fft.fft(full, axis=1)
     for f in range(frames):
-        if mode in (0, 1):
-            for v in range(V):
-                ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L     # the kernels leave the 1/L to psf_hat's scale
-                assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
-        else:
+        if sum_views:
             ref = np.fft.ifft(sum(spec[f * V + v] * ph[v].T for v in range(V)), axis=0)[:ny] * L
             assert max_rel(out[f][:, :kx], ref) < 1e-12, f
-
-
-def _blocked4(x):
-    """Row-major spectra (n, ny, pitch) -> the 4 x 4 blocked layout of conv_kernels.hpp spec_off4 (rows padded to a multiple of 4)."""
-    n, ny, pitch = x.shape
-    r4 = (ny + 3) // 4 * 4
-    full = np.full((n, r4, pitch), np.nan, dtype=x.dtype)
-    full[:, :ny] = x
-    return np.ascontiguousarray(full.reshape(n, r4 // 4, 4, pitch // 4, 4).transpose(0, 1, 3, 2, 4)).reshape(n, r4, pitch)
-
-
-@pytest.mark.parametrize('Li,C,ny,kx,real_psf', [(256, 4, 1001, 6, 1), (576, 1, 2048, 1, 0), (256, 2, 603, 3, 1)])
-def test_four_wave_view_sum_reads_blocked_ratio_spectra(emu, Li, C, ny, kx, real_psf):
-    """ColParams::in_blocked4: COL_HT_SUM of colconv_outer4_body takes its input in the 4 x 4 blocked layout (one 128-byte line
-    = 4 rows x 4 columns, so the four wave groups of a workgroup share the lines they fetch) and gives the row-major result
-    of the row-major input; heights that are not multiples of 4, partial column tiles."""
-    emu.emu_set_blocked4.argtypes = [ctypes.c_int]
-    L, V, frames = 4 * Li, 3, 2
-    pitch = (kx + 7) // 8 * 8
-    rng = np.random.default_rng(Li + ny + C)
-    x = np.zeros((frames * V, ny, pitch), dtype=np.complex128)
-    x[:, :, :kx] = rng.standard_normal((frames * V, ny, kx)) + 1j * rng.standard_normal((frames * V, ny, kx))
-    ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
-    psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
-    outs = []
-    for blocked in (0, 1):
-        out = np.full((frames, ny, pitch), np.nan + 0j, dtype=np.complex128)
-        try:
-            emu.emu_set_blocked4(blocked)
-            rc = emu.emu_col_outer4_f64(Li, C, 2, _p(_slack(_blocked4(x) if blocked else x)), _p(out), _p(psf_arg), real_psf, ny, kx,
-                                        pitch, V, frames, 1, 0)
-        finally:
-            emu.emu_set_blocked4(0)
-        assert rc == 0
-        outs.append(out[:, :, :kx])
-    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize('Lx,ny,nx', [(192, 7, 150), (256, 10, 200), (576, 5, 512)])
-def test_ratio_rows_store_the_blocked_layout(emu, Lx, ny, nx):
-    """RowParams::out_blocked4: ROW_RATIO writes the same values, at spec_off4 -- the generic body (192) and the lean one (256, 576)."""
-    emu.emu_set_blocked4.argtypes = [ctypes.c_int]
-    rng = np.random.default_rng(Lx + ny)
-    pl = EmuPlan(emu, [np.ones((1, 3, 3)) / 9], ny, nx, 64, Lx)
-    gy = 3
-    sin = pl.spec(gy)
-    rows = np.zeros((gy, ny, Lx))
-    rows[:, :, :nx] = rng.random((gy, ny, nx)) + 0.5                 # a positive H(est), so that the ratio is finite
-    sin[...] = 0
-    sin[:, :, :pl.kx] = np.fft.rfft(rows, axis=2) / Lx
-    meas = _slack(rng.random((gy, ny, nx)) * 30)
-    plain = pl.spec(gy)
-    pl._row(ROW_RATIO, gy, sin, plain, meas, None, None, None)
-    r4 = (ny + 3) // 4 * 4
-    blk = _slack(np.full((gy, r4, pl.pitch), np.nan + 0j, dtype=np.complex128))
-    try:
-        emu.emu_set_blocked4(1)
-        pl._row(ROW_RATIO, gy, sin, blk, meas, None, None, None)
-    finally:
-        emu.emu_set_blocked4(0)
-    want = np.full((gy, ny, pl.pitch), np.nan + 0j)
-    want[:, :, :pl.kx] = plain[:, :, :pl.kx]
-    got = _blocked4(want)
-    mask = np.isfinite(got)                      # (columns >= kx and the pad rows: never written, whatever the layout)
-    assert mask.sum() == gy * ny * pl.kx and np.array_equal(blk[mask], got[mask])
-    assert np.isnan(blk[~mask]).all()
+        else:
+            for v in range(V):
+                ref = np.fft.ifft(spec[f] * ph[v].T, axis=0)[:ny] * L
+                assert max_rel(out[f * V + v][:, :kx], ref) < 1e-12, (f, v)
 
 
 # ------------------------------------------------- frame pairs: two frames in one complex image

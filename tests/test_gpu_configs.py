@@ -109,10 +109,11 @@ def test_large_tiles_f32_vs_f64_plan(lib, golden, size):
 
 @pytest.mark.parametrize('ny,nx,views', [(2048, 2048, 2), (1024, 1024, 4), (2048, 2048, 5), (600, 4096, 3)])
 def test_multi_view_long_transforms_f32_vs_f64_plan(lib, golden, ny, nx, views):
-    """Multi-view plans on the long transforms, f32 against the f64 plan (same noisy measurement, K = 20).  Two views at
-    L = 2304, and every view count at 1152 / 4608, run V per-image column launches and the pre-summed update (rowpass_body
-    PRESUM: the views' `ratio - 1` spectra are added on their way in, ONE inverse row transform, the sum clamped); three
-    views or more at L = 2304 the Fourier-domain view sum over the 4 x 4 blocked ratio spectra (colconv_outer4_body)."""
+    """Multi-view plans on the long transforms, f32 against the f64 plan (same noisy measurement, K = 20).  L = 1152 runs V
+    per-image column launches (colconv_outer_body, M = 2) and the pre-summed update (rowpass_body PRESUM: the views'
+    `ratio - 1` spectra are added on their way in, ONE inverse row transform, the sum clamped); L = 2304 / 4608 the split
+    column pass (COL_SPLIT_FWD / COL_SPLIT_INV / COL_SPLIT_INV_SUM: the views' products summed before one inverse column
+    transform)."""
     g = golden('g8_fig2_psfs')
     base = g['2p0x_lr/line_sted_psfs'][:, 0]
     psfs = [np.roll(base[v % len(base)], v // len(base), axis=1)[None] for v in range(views)]
