@@ -511,7 +511,10 @@ def main():
         'note': 'priced against the HBM roofline as BASELINE.json asks; the SQ counters (profiles/r03/sq_counters_512.txt) show the '
                 'three RL kernels 80-90 % VALU-active when they run alone: fp32 vector issue, not memory, is what the path waits for '
                 '(DESIGN.md section 4)',
-        'kernel': 'one RL iteration over one slice = 4 launches: k_colconv, k_rowpair<RATIO>, k_colconv, k_rowpair<UPDATE>',
+        'kernel': ('one RL iteration over one slice = 6 launches: split column pass of H (k_colconv_outer<FWD>, <INV>), k_rowpass<RATIO>, '
+                   'split column pass of H_t (k_colconv_outer<FWD>, <INV_SUM>), k_rowpass<UPDATE>; colconv_H / colconv_Ht = both halves'
+                   if (not stub and plan.strategy().get('split_column_pass')) else
+                   'one RL iteration over one slice = 4 launches: k_colconv, k_rowpair<RATIO>, k_colconv, k_rowpair<UPDATE>'),
         'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
         'algorithmic_bytes': alg_iter, 'traffic': traffic, 'traffic_over_algorithmic': traffic / alg_iter if traffic else None,
         'traffic_per_kernel': per_kernel_traffic, 'traffic_source': pmc_file,

@@ -136,15 +136,16 @@ int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements
 /* Convolution strategy the plan chose for its PSF set: separable != 0: every view
  * is rank 1 (p = u v^T; the 0 / 90 degree line PSFs) and small, H / H_t run as direct row + column stencils;
  * otherwise the FFT path, with real_psf_spectrum != 0 when the (point-symmetric) PSFs' spectra are real and
- * the column kernels multiply by their real parts alone; *fused_rl is always 0 (the persistent XCD-resident
- * Richardson-Lucy kernel of round 2 was measured, lost and removed; the parameter keeps the signature);
+ * the column kernels multiply by their real parts alone; split_column_pass != 0: a multi-view f32 plan on the long
+ * column transforms (L = 2304, 4608), whose column passes are two launches each -- forward half, inverse half, the
+ * column spectra parked between them (this slot reported the removed fused kernel of round 2 and was always 0);
  * frame_pairs != 0: the Richardson-Lucy loop transforms frames 2p and 2p+1 as the real and imaginary part of one
  * complex image (single-view f32 plans by default: RLSTED_PAIR) -- a frame's estimate then depends on its partner
  * at f32 rounding level (~1e-7 of the brighter partner's scale).  The answer is the loop that will run on the
  * CURRENT data: a plan built with pairs runs its per-frame loop while any pair's frames differ in level (sum of the
  * object / measurement) by more than a factor of 4 (RLSTED_PAIR_MAX_RATIO), because a dim frame would inherit
  * the rounding error of a bright partner.  Any of the pointers may be NULL.                                  */
-int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl, int* frame_pairs);
+int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* split_column_pass, int* frame_pairs);
 
 /* Plan geometry: frames per plan, views per frame, image shape.                */
 int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx);

@@ -1420,12 +1420,12 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
 }
 
 
-int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* fused_rl, int* frame_pairs) {
+int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* split_column_pass, int* frame_pairs) {
     if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
     if (frame_pairs) *frame_pairs = h->pair ? 1 : 0;
     if (separable) *separable = h->sep ? 1 : 0;
     if (real_psf_spectrum) *real_psf_spectrum = h->psf_hat_re ? 1 : 0;
-    if (fused_rl) *fused_rl = 0;   // (the persistent XCD-resident loop of round 2 lost to the four-launch iteration and was removed)
+    if (split_column_pass) *split_column_pass = !h->sep && !h->pair && h->col_split() ? 1 : 0;
     return RL_OK;
 }
 

@@ -325,6 +325,7 @@ def test_split_column_pass_against_whole_pass(lib, golden, ny, nx, B, monkeypatc
         monkeypatch.setenv('RLSTED_COL_SPLIT', flag)
         plan = lib.DeconvPlan(psfs, B, ny, nx, dtype='f32')
         assert plan.info()['ly'] == (4608 if ny > 2048 else 2304)
+        assert plan.strategy()['split_column_pass'] == (flag == '1')
         plan.set_object(obj, 5e10 * ny * nx / 128 ** 2)
         plan.simulate(seed=9)
         plan.iterate(3)

@@ -24,7 +24,9 @@ NAMES = (  # (regex on the kernel name, key in the json); first match wins
     (r'k_rowpass<\d+, \d+, 0,', 'rowpass_FWD'), (r'k_rowpass<\d+, \d+, 1,', 'rowpass_INV'),
     (r'k_rowpass<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpass<\d+, \d+, 3,', 'rowpass_UPDATE'),
     (r'k_rowpass<\d+, \d+, 4,', 'rowpass_ADJ'),
-    (r'k_colconv_outer4<\d+, \d+, \w+, 2>', 'colconv_Ht'), (r'k_colconv_outer4<\d+, \d+, \w+, 1>', 'colconv_H'),
+    # the split column pass of multi-view plans on the long transforms (conv_kernels.hpp COL_SPLIT_FWD / _INV / _INV_SUM)
+    (r'k_colconv_outer<\d+, \d+, \w+, 3>', 'colsplit_FWD'), (r'k_colconv_outer<\d+, \d+, \w+, 4>', 'colsplit_INV'),
+    (r'k_colconv_outer<\d+, \d+, \w+, 5>', 'colsplit_INV_SUM'),
     (r'k_colconv<\d+, \d+, 2,', 'colconv_Ht'), (r'k_colconv<\d+, \d+, 1,', 'colconv_H'),
     (r'k_colconv', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'))
 
@@ -45,6 +47,12 @@ def per_kernel(path, counter):
         common = max(set(grids), key=grids.count)     # the launch shape that dominates the run
         sel = [x for g, x in v if g == common]
         out[key] = sum(sel) / len(sel)
+        if key == 'colsplit_FWD':
+            # two shapes per RL iteration: the slice's frames (H) and its frames x views images (H_t)
+            top = sorted(sorted(set(grids), key=grids.count)[-2:])
+            for g, name in zip(top, ('colsplit_FWD_frames', 'colsplit_FWD_images')):
+                sel = [x for gg, x in v if gg == g]
+                out[name] = sum(sel) / len(sel)
     return out
 
 
@@ -60,6 +68,12 @@ def main():
         # FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: Infinity Cache hits are counted too, so
         # this is fabric traffic (what leaves the XCD's L2), not bytes that reached HBM
         res[key] = {'fabric_bytes_per_launch': 2 * f * 1024 + w * 1024, 'fetch_kb_reported': f, 'write_kb_reported': w}
+    if all(k in res for k in ('colsplit_FWD_frames', 'colsplit_FWD_images', 'colsplit_INV', 'colsplit_INV_SUM')):
+        # a column pass of these plans is two launches: forward half + inverse half
+        for k, parts in (('colconv_H', ('colsplit_FWD_frames', 'colsplit_INV')), ('colconv_Ht', ('colsplit_FWD_images', 'colsplit_INV_SUM'))):
+            res[k] = {'fabric_bytes_per_launch': sum(res[q]['fabric_bytes_per_launch'] for q in parts),
+                      'fetch_kb_reported': sum(res[q]['fetch_kb_reported'] for q in parts),
+                      'write_kb_reported': sum(res[q]['write_kb_reported'] for q in parts), 'launches': list(parts)}
     if 'colconv' in res:   # the H and H_t column passes are the same kernel (single view / per-image launches)
         for k in ('colconv_H', 'colconv_Ht'):
             res.setdefault(k, res['colconv'])
