@@ -201,6 +201,9 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
 //                  in the Fourier domain and inverse transformed once -> output image frame
 //                  (H_t, ref:584-588, with the per-view clamp replaced by one clamp of the sum:
 //                  identical in exact arithmetic, see DESIGN.md "fused views")
+#ifndef RL_SPLIT_PREFETCH
+#define RL_SPLIT_PREFETCH 1
+#endif
 enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
                // the split column pass of colconv_outer_body (round 3): forward half -> column spectra in register-slot order,
                // inverse half from there -- one image per launch row, or the V views of a frame summed
@@ -409,6 +412,24 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
 
     // residue class q of the tile: element e = tid + it*NT <-> (m = e / C, column c = e % C), row M*m + q
+    // (fetch_class / park_class: the global loads of a class and their way into LDS, apart -- COL_SPLIT_FWD requests the next
+    // class's rows before it transforms the current one)
+    auto fetch_class = [&](const cx<T>* __restrict__ in, int q, cx<T> (&x)[NLD]) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            const int row = M * (e / C) + q, c = e % C;
+            x[it] = mk<T>((T)0, (T)0);
+            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
+        }
+    };
+    auto park_class = [&](const cx<T> (&x)[NLD]) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * NT;
+            lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
+        }
+    };
     auto load_class = [&](const cx<T>* __restrict__ in, int q) {
         cx<T> x[NLD];
 #pragma unroll
@@ -450,6 +471,24 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     using Regs = cx<T>[M][NV + 1];   // [q][slot]; slot NV = tail element (unused when the core has none)
     // Y <- the M core transforms of the residue classes of image `in`; `first`: no workgroup is still reading LDS
     auto forward_classes = [&](const cx<T>* __restrict__ in, Regs& Y, bool first) {
+        if constexpr (MODE == COL_SPLIT_FWD && RL_SPLIT_PREFETCH) {
+            cx<T> x[NLD];
+            fetch_class(in, 0, x);
+#pragma unroll
+            for (int q = 0; q < M; ++q) {
+                if (q > 0) sync.wg();
+                park_class(x);
+                if (q + 1 < M) fetch_class(in, q + 1, x);     // in flight while this class is transformed
+                sync.wg();
+                cx<T> v[VMAX];
+                cx<T> tl = mk<T>((T)0, (T)0);
+                if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+#pragma unroll
+                for (int s = 0; s < NV; ++s) Y[q][s] = v[s];
+                Y[q][NV] = tl;
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < M; ++q) {
             if (q > 0 || !first) sync.wg();          // every wave is done with the previous class in LDS
