@@ -471,7 +471,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     using Regs = cx<T>[M][NV + 1];   // [q][slot]; slot NV = tail element (unused when the core has none)
     // Y <- the M core transforms of the residue classes of image `in`; `first`: no workgroup is still reading LDS
     auto forward_classes = [&](const cx<T>* __restrict__ in, Regs& Y, bool first) {
-        if constexpr (MODE == COL_SPLIT_FWD && RL_SPLIT_PREFETCH) {
+        if constexpr (MODE == COL_SPLIT_FWD && RL_SPLIT_PREFETCH) {   // (the same in the whole kernel: measured neutral, +-1 %)
             cx<T> x[NLD];
             fetch_class(in, 0, x);
 #pragma unroll
