@@ -390,7 +390,11 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 // It loads all M blocks before the first transform and keeps all M x 9 values live through every core transform;
 // the residue-class form below interleaves loads and transforms and lets the live set grow with them.)
 // Twiddles: p.tw = [core table PassTw<Cfg>][ (M-1) x Li entries W_L^(q k), q = 1 .. M-1 ].
-template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, class Sync>
+// PARK (whole pass only): that many of the waiting core results per lane -- classes 0, 1, ... on the way in, M-1, M-2, ... on the
+// way back -- wait in LDS instead of registers ([value][thread] behind the transform regions: private to the thread, no barrier).
+// The whole pass needs 4 x 10 (8 x 10) values per lane beside a core transform's working set and spills 25-31 dwords per lane
+// at the register budget its residency allows: scratch that streams through HBM (7.4 MB each way per 2048^2 image).
+template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, int PARK = 0, class Sync>
 RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "the core must be a wave-private transform");
     static_assert(M == 2 || M == 4 || M == 8, "outer radix 2, 4 or 8");
@@ -563,7 +567,87 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     // with one register set: neither half keeps a second set alive the way the fused multi-view modes must.
     const size_t xs_img = (size_t)((p.kx + C - 1) / C) * (NV + 1) * M * NT;
     auto xs_at = [&](int s, int j) -> size_t { return (((size_t)bx * (NV + 1) + s) * M + j) * NT + tid; };
-    if constexpr (MODE == COL_PER_IMAGE) {
+    if constexpr (MODE == COL_PER_IMAGE && PARK > 0) {
+        static_assert(PARK <= (M - 1) * (NV + 1), "at most all classes but the one being transformed");
+        const int frame = by / p.V, view = by % p.V;
+        const cx<T>* __restrict__ in = p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img;
+        cx<T>* __restrict__ out = p.out + (size_t)by * img;
+        cx<T>* __restrict__ const park = lds + C * LP + tid;       // value e of this thread at park[e * NT]
+        Regs Y;
+        // forward: as forward_classes(), a finished class goes to the parking space while the later ones are transformed
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            if (q > 0) sync.wg();
+            load_class(in, q);
+            sync.wg();
+            cx<T> v[VMAX];
+            cx<T> tl = mk<T>((T)0, (T)0);
+            if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+#pragma unroll
+            for (int s = 0; s <= NV; ++s) {
+                const cx<T> val = s == NV ? tl : v[s];
+                if (q * (NV + 1) + s < PARK) park[(q * (NV + 1) + s) * NT] = val;
+                else Y[q][s] = val;
+            }
+        }
+        // the radix-M steps and the multiplier, slot by slot: a parked value comes straight from its place, and the place takes the
+        // value that waits for the inverse of class M-1, M-2, ... (same slot: read before written)
+        // (M = 8, 256 registers: all of them back in registers for the loop -- the compiler's allocation: 0-8 bytes of scratch
+        // against 40-60 the other way; M = 4, 128 registers: 76-84 bytes in place against 52-124)
+        constexpr bool IN_PLACE = M <= 4;
+        if constexpr (!IN_PLACE) {
+#pragma unroll
+            for (int e = 0; e < PARK; ++e) Y[e / (NV + 1)][e % (NV + 1)] = park[e * NT];
+        }
+        if (colok) {
+            RL_FOR_LIVE_SLOTS(s) {
+                cx<T> u[M];
+                if constexpr (IN_PLACE) {
+#pragma unroll
+                    for (int q = 0; q < M; ++q)
+                        if (q * (NV + 1) + s < PARK) Y[q][s] = park[(q * (NV + 1) + s) * NT];
+                }
+                slot_spectrum(Y, s, view, u);
+                slot_classes(u, s, Y);
+                if constexpr (IN_PLACE) {
+#pragma unroll
+                    for (int q = 0; q < M; ++q)
+                        if ((M - 1 - q) * (NV + 1) + s < PARK) park[((M - 1 - q) * (NV + 1) + s) * NT] = Y[q][s];
+                }
+            }
+        }
+        if constexpr (!IN_PLACE) {
+#pragma unroll
+            for (int e = 0; e < PARK; ++e) park[e * NT] = Y[M - 1 - e / (NV + 1)][e % (NV + 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            sync.wg();
+            if (colok) {
+                cx<T> v[VMAX];
+                cx<T> tl;
+#pragma unroll
+                for (int s = 0; s <= NV; ++s) {
+                    const int e = (M - 1 - q) * (NV + 1) + s;
+                    const cx<T> val = e < PARK ? park[e * NT] : Y[q][s];
+                    if (s == NV) tl = val;
+                    else v[s] = val;
+                }
+                run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
+                sync.wave();
+#pragma unroll
+                for (int nb = 0; nb < IL::NB; ++nb) {
+                    const int j = lane + nb * 64;
+                    if (j < IL::NBF) {
+#pragma unroll
+                        for (int r = 0; r < IL::R; ++r) view_lds.template at_step<IL::NBF>(j, view_lds.nat(j), r) = v[nb * IL::R + r];
+                    }
+                }
+            }
+            sync.wg();
+            store_class(out, q);
+        }
+    } else if constexpr (MODE == COL_PER_IMAGE) {
         const int frame = by / p.V, view = by % p.V;
         Regs Y;
         forward_classes(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img, Y, true);

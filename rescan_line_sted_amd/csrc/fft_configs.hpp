@@ -164,6 +164,7 @@ struct OuterCol {
     using Core = typename CfgFor<64>::Cfg;   // unused
     static constexpr int M = 2, C = 8, MIN_WAVES = 1;
     static constexpr bool SPLIT = false;                 // the split pass (COL_SPLIT_*) is what multi-view f32 plans run
+    static constexpr int PARK = 0;                       // waiting core results per lane the whole pass keeps in LDS (colconv_outer_body)
 };
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
@@ -187,6 +188,10 @@ struct OuterCol<2304> {
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
     static constexpr bool SPLIT = true;    // 2048^2: 4 views 215 -> 236-244 frames/s, 2 views 407 -> 414
+#ifndef RL_PARK_2304
+#define RL_PARK_2304 7
+#endif
+    static constexpr int PARK = RL_PARK_2304;   // 7 values x 512 threads = 28.7 KB beside the 51.3 KB of transforms: two workgroups per CU still fit
 };
 // 1152 = 2 x 576 (round 3, for the split pass of multi-view plans; as a whole-pass kernel it measured 1.32 -> 1.14 us alone and
 // no gain in the 1024^2 single-view loop in round 2)
@@ -201,6 +206,7 @@ struct OuterCol<1152> {
     // measured at 1024^2 (frames/s; (8,9,16) x 144 workgroup-synchronous kernel / this body per image / its split pass):
     // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -
     static constexpr bool SPLIT = false;
+    static constexpr int PARK = 0;   // (2 x 10 values per lane: nothing spills)
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
@@ -214,6 +220,10 @@ struct OuterCol<4608> {
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 8, C = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
     static constexpr bool SPLIT = true;    // 4096^2, 4 views: 33.5 -> 45 frames/s
+#ifndef RL_PARK_4608
+#define RL_PARK_4608 20
+#endif
+    static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 82 KB of parking space beside 51.3 KB
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_oute
             by = w / gx;
         }
     }
-    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
+    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE, (MODE == COL_PER_IMAGE ? OC::PARK : 0)>(p, (int)threadIdx.x, (int)bx, (int)by,
+                                                                                                             reinterpret_cast<cx<float>*>(smem), s);
 }
 template <int L>
 static void fill_outer_twiddles(double* out) {
@@ -287,8 +288,9 @@ static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigne
                 return hipGetLastError();
             }
             if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
-            if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds, s, p);
-            else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false>, grid, block, lds, s, p);
+            constexpr size_t lds_whole = lds + (size_t)OC::PARK * 64 * OC::C * sizeof(cx<float>);   // + the parking space
+            if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds_whole, s, p);
+            else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false>, grid, block, lds_whole, s, p);
             return hipGetLastError();
         }
     }
@@ -351,8 +353,10 @@ static hipError_t prepare() {
     if constexpr (OuterCol<RL_CFG_L>::value) {
         using OC = OuterCol<RL_CFG_L>;
         constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds)) != hipSuccess) return e;
+        constexpr size_t lds_whole = lds + (size_t)OC::PARK * 64 * OC::C * sizeof(cx<float>);
+        static_assert(lds_whole <= 160 * 1024, "LDS of a CU");
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds_whole)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds_whole)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, lds)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, lds)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, lds)) != hipSuccess) return e;

@@ -177,6 +177,7 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
 extern "C" {
 
 void emu_set_sub_one(int on) { g_sub_one = on; }
+void emu_set_park(int on);
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
 int emu_geometry(int L, int* T, int* C, int* Q) {
@@ -211,6 +212,8 @@ int emu_row_pair_f32(int L, int mode, const float* spec_in, float* spec_out, con
 // colconv_outer_body (long column transforms on a wave-private core): L = M * Li, Li in {256, 576}.
 // psf_hat: complex [V][kx][L] (transposed layout), or -- real_psf -- its real parts [V][kx][L].
 }  // extern "C"
+// ColParams-independent: waiting core results per lane kept in LDS by the whole pass (conv_kernels.hpp PARK); 0 = none
+static int g_park = 0;
 template <class Core, int M, typename T>
 static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
                        int in_sb, int in_sv, int mode = COL_PER_IMAGE) {
@@ -234,6 +237,16 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
     p.tw = tw.data();
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
     p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
+    if (g_park) {   // the device's choices: 7 of the 4 x 10 values (L = 2304), 20 of the 8 x 10 (L = 4608); M = 2: 5
+        constexpr int PARK = M == 4 ? 7 : M == 8 ? 20 : 5;
+        run_grid((kx + C - 1) / C, p.images, 64 * C, ((size_t)C * LdsSlots<Core>::value + (size_t)PARK * 64 * C) * sizeof(cx<T>),
+                 [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                     cx<T>* l = reinterpret_cast<cx<T>*>(lds);
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_PER_IMAGE, PARK>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_PER_IMAGE, PARK>(p, tid, bx, by, l, s);
+                 });
+        return 0;
+    }
     run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  cx<T>* l = reinterpret_cast<cx<T>*>(lds);
@@ -329,6 +342,7 @@ int emu_row_pair_f32(int L, int mode, const float* spec_in, float* spec_out, con
                      int ny, int nx, int frames, int in_mod) {
     DISPATCH_L(L, (row_pair_t<LL, float>(mode, spec_in, spec_out, src, dst, norm, ny, nx, frames, in_mod)))
 }
+void emu_set_park(int on) { g_park = on; }
 int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double* psf_hat, int real_psf, int ny, int kx,
                       int pitch, int V, int frames, int in_sb, int in_sv) {
     using C256 = CfgFor<256>::Cfg;

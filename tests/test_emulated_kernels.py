@@ -356,9 +356,13 @@ def test_ratio_minus_one_l576_f32(emu):
 # ------------------------------------------------- long column transforms on the wave-private core
 @pytest.mark.parametrize('Li,M,ny,kx,real_psf', [(256, 4, 900, 11, 0), (256, 2, 437, 8, 1), (576, 4, 2048, 9, 0),
                                                    (576, 4, 2001, 3, 1), (256, 8, 1900, 5, 0), (576, 8, 4096, 2, 1)])
-def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
+@pytest.mark.parametrize('park', [0, 1])
+def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf, park):
     """colconv_outer_body: L = M * Li as M core transforms plus one radix-M step in registers (the f32
-    column kernel of L = 2304 = 4 x 576 and 4608 = 8 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat), rows < ny."""
+    column kernel of L = 1152 = 2 x 576, 2304 = 4 x 576 and 4608 = 8 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat),
+    rows < ny.  park: some of the waiting core results per lane wait in LDS instead of registers (PARK: 7 of 4 x 10 used in place
+    during the radix-4 steps, 20 of 8 x 10 brought back for them) -- the same values either way."""
+    emu.emu_set_park.argtypes = [ctypes.c_int]
     L, V, frames = M * Li, 2, 1
     pitch = (kx + 7) // 8 * 8
     rng = np.random.default_rng(Li + M + ny)
@@ -367,7 +371,11 @@ def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf):
     ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
     out = np.zeros((frames * V, ny, pitch), dtype=np.complex128)
     psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
-    rc = emu.emu_col_outer_f64(Li, M, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, 1, 0)
+    try:
+        emu.emu_set_park(park)
+        rc = emu.emu_col_outer_f64(Li, M, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, 1, 0)
+    finally:
+        emu.emu_set_park(0)
     assert rc == 0
     full = np.zeros((frames, L, kx), dtype=np.complex128)
     full[:, :ny] = x[:, :, :kx]
