@@ -198,11 +198,14 @@ struct OuterCol<2304> {
 #ifndef RL_OUTER_1152
 #define RL_OUTER_1152 1
 #endif
+#ifndef RL_OUTER_1152_MIN_WAVES
+#define RL_OUTER_1152_MIN_WAVES 4      // (6 = three workgroups per CU at 80 registers + 48 bytes of scratch: 1024^2 x 4 views 1025 -> 890 frames/s)
+#endif
 template <>
 struct OuterCol<1152> {
     static constexpr bool value = RL_OUTER_1152 != 0;
     using Core = typename CfgFor<576>::Cfg;
-    static constexpr int M = 2, C = 8, MIN_WAVES = 4;
+    static constexpr int M = 2, C = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
     // measured at 1024^2 (frames/s; (8,9,16) x 144 workgroup-synchronous kernel / this body per image / its split pass):
     // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -
     static constexpr bool SPLIT = false;
