@@ -68,6 +68,11 @@ def workload(size, n_views=None):
         name = ('astronaut 128->512x512 (np.kron x4), point-descan STED PSF 107x107 (2.0x operating point), '
                 'simulate (H + Philox Poisson) + 20 RL iterations per frame')
         return obj, psf, 5e10 * 16, name
+    if (n_views or 4) == 1:     # config 5's tile: one large white-noise frame, point-descan PSF
+        obj = np.random.default_rng(4321).random((size, size)) * 255.0
+        return obj, [psfs['2p0x_lr/point_sted_psf'][0]], 5e10 * (size // 128) ** 2, (
+            'default_rng(4321) uniform %dx%d object, point-descan STED PSF 107x107 (2.0x operating point), simulate (H + Philox '
+            'Poisson) + RL iterations per frame (BASELINE config 5 tile)' % (size, size))
     obj = np.random.default_rng(1234).random((size, size)) * 255.0
     psf = [p[None] for p in psfs['2p0x_lr/line_sted_psfs'][:, 0]]
     name = ('default_rng(1234) uniform %dx%d object, line-rescan STED, 4 views 107x107 (2.0x operating point), '
@@ -273,26 +278,27 @@ def accuracy(plan, psf, size, dtype):
             'contract': 1e-5 if dtype == 'f32' else 1e-10}
 
 
-def extra_leg(size, n_views, dtype, B, steps, warmup, device):
+def extra_leg(size, n_views, dtype, B, steps, warmup, device, k_iters=K_ITERS):
     """`steps` whole cycles (simulate + 20 RL iterations) of `B` frames of another workload shape, timed like the
     headline (synchronise, wall clock, synchronise): BASELINE config 3 (2048 x 2048 line-rescan), config 2's line-rescan
-    half (512 x 512, 4 views) and the headline in the reference's own arithmetic (float64 plan)."""
+    half (512 x 512, 4 views), the headline in the reference's own arithmetic (float64 plan) and config 5's 4096 x 4096
+    tile at its 100 iterations."""
     from rescan_line_sted_amd import _lib
     obj, psf, brightness, name = workload(size, n_views)
     plan = _lib.DeconvPlan(psf, B, size, size, dtype=dtype, device=device)
     plan.set_object(np.broadcast_to(obj, (B, size, size)), brightness)
     for w in range(warmup):
-        plan.bench_cycles(K_ITERS, 1, seed=w)
+        plan.bench_cycles(k_iters, 1, seed=w)
     plan.ctx.synchronize()
     t0 = time.perf_counter()
-    plan.bench_cycles(K_ITERS, steps, seed=warmup)
+    plan.bench_cycles(k_iters, steps, seed=warmup)
     plan.ctx.synchronize()
     el = time.perf_counter() - t0
     est = plan.estimate()
     assert np.isfinite(est).all() and est.min() >= 0
     value = B * steps / el
     es = 4 if dtype == 'f32' else 8
-    alg = algorithmic_bytes_per_frame(size * size, len(psf), K_ITERS) * es // 4
+    alg = algorithmic_bytes_per_frame(size * size, len(psf), k_iters) * es // 4
     info = plan.info()
     fabric = None       # fabric bytes / algorithmic bytes of one RL iteration at this launch shape, where the PMC passes were recorded
     try:
@@ -301,9 +307,9 @@ def extra_leg(size, n_views, dtype, B, steps, warmup, device):
             fabric = pmc.get('rl_iteration')
     except (OSError, ValueError):
         pass
-    return {'metric': 'simulated frames/s (%dx%d, 20 RL iters)' % (size, size), 'value': value, 'unit': 'frames/s',
+    return {'metric': 'simulated frames/s (%dx%d, %d RL iters)' % (size, size, k_iters), 'value': value, 'unit': 'frames/s',
             'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3, 'dtype': dtype,
-            'config': {'workload': name, 'frames_per_gpu_per_step': B, 'n_psf': len(psf), 'rl_iters': K_ITERS,
+            'config': {'workload': name, 'frames_per_gpu_per_step': B, 'n_psf': len(psf), 'rl_iters': k_iters,
                        'fft': '%dx%d' % (info['ly'], info['lx']), 'frame_pairs': plan.strategy()['frame_pairs']},
             'whole_path': {'algorithmic_bytes_per_frame': alg, 'bytes_per_element': es, 'GBps': alg * value / 1e9,
                            'frac': alg * value / 1e9 / HBM_PEAK_GBS},
@@ -547,10 +553,11 @@ def main():
     # headline): BASELINE config 3 (2048^2 line-rescan), config 2's line-rescan half, the reference's float64 arithmetic
     if size == 512 and world == 1 and comm is None and not stub and not args.no_extra and args.dtype == 'f32':
         del plan
-        for key, leg in (('size_2048', (2048, 4, 'f32', 32, 3, 1)), ('line_rescan_512', (512, 4, 'f32', 128, 5, 1)),
-                         ('f64_512', (512, 1, 'f64', 128, 5, 1))):
+        for key, leg, k in (('size_2048', (2048, 4, 'f32', 32, 3, 1), K_ITERS), ('line_rescan_512', (512, 4, 'f32', 128, 5, 1), K_ITERS),
+                            ('f64_512', (512, 1, 'f64', 128, 5, 1), K_ITERS), ('point_2048', (2048, 1, 'f32', 32, 3, 1), K_ITERS),
+                            ('size_4096_k100', (4096, 1, 'f32', 8, 2, 1), 100)):
             try:
-                out[key] = extra_leg(*leg, local_rank)
+                out[key] = extra_leg(*leg, local_rank, k)
             except Exception as exc:     # reported, never allowed to void the headline
                 out[key] = {'error': repr(exc)}
     # BASELINE config 4 through the sharder: whenever there is more than one rank, or on request
