@@ -394,7 +394,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 // way back -- wait in LDS instead of registers ([value][thread] behind the transform regions: private to the thread, no barrier).
 // The whole pass needs 4 x 10 (8 x 10) values per lane beside a core transform's working set and spills 25-31 dwords per lane
 // at the register budget its residency allows: scratch that streams through HBM (7.4 MB each way per 2048^2 image).
-template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, int PARK = 0, class Sync>
+template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, int PARK = 0, int TWLDS = 0, class Sync>
 RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "the core must be a wave-private transform");
     static_assert(M == 2 || M == 4 || M == 8, "outer radix 2, 4 or 8");
@@ -412,7 +412,20 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     const int col0 = bx * C, col = col0 + w;
     const bool colok = col < p.kx;
     const size_t img = spec_image_elems(p.ny, p.pitch);
-    const cx<T>* __restrict__ ctw = p.tw + PassTw<Cfg, false, 0>::TOTAL;   // W_L^(q k) at (q - 1) * Li + k
+    // TWLDS: the core's twiddle table (2016 entries for 576; TWLDS = 2: the (M - 1) x Li outer twiddles behind it too) is copied
+    // behind the parking space once per workgroup and read from there: one workgroup per CU exposes every L1 round trip, and 70 % of
+    // this body's vector-memory reads are twiddles
+    const cx<T>* tw_core = p.tw;
+    const cx<T>* ctw = p.tw + PassTw<Cfg, false, 0>::TOTAL;   // W_L^(q k) at (q - 1) * Li + k
+    if constexpr (TWLDS > 0) {
+        constexpr int NTW = PassTw<Cfg, false, 0>::TOTAL + (TWLDS > 1 ? (M - 1) * Li : 0);
+        cx<T>* const tw_lds = lds + C * LP + PARK * NT;
+        for (int e = tid; e < NTW; e += NT) tw_lds[e] = p.tw[e];
+        tw_core = tw_lds;      // (the first workgroup barrier of the pass stands between this copy and its first use)
+        if constexpr (TWLDS > 1) ctw = tw_lds + PassTw<Cfg, false, 0>::TOTAL;
+        // (the inverse halves of the split pass use the outer twiddles before their first barrier)
+        if constexpr (TWLDS > 1 && (MODE == COL_SPLIT_INV || MODE == COL_SPLIT_INV_SUM)) sync.wg();
+    }
     LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
 
     // residue class q of the tile: element e = tid + it*NT <-> (m = e / C, column c = e % C), row M*m + q
@@ -486,7 +499,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
                 sync.wg();
                 cx<T> v[VMAX];
                 cx<T> tl = mk<T>((T)0, (T)0);
-                if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+                if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw_core, sync);
 #pragma unroll
                 for (int s = 0; s < NV; ++s) Y[q][s] = v[s];
                 Y[q][NV] = tl;
@@ -500,7 +513,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
             sync.wg();
             cx<T> v[VMAX];
             cx<T> tl = mk<T>((T)0, (T)0);
-            if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+            if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw_core, sync);
 #pragma unroll
             for (int s = 0; s < NV; ++s) Y[q][s] = v[s];
             Y[q][NV] = tl;
@@ -541,7 +554,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
 #pragma unroll
                 for (int s = 0; s < NV; ++s) v[s] = Z[q][s];
                 cx<T> tl = Z[q][NV];
-                run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
+                run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw_core, sync);
                 sync.wave();   // last pass' LDS reads are done before the column is overwritten
 #pragma unroll
                 for (int nb = 0; nb < IL::NB; ++nb) {
@@ -582,7 +595,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
             sync.wg();
             cx<T> v[VMAX];
             cx<T> tl = mk<T>((T)0, (T)0);
-            if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+            if (colok) run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw_core, sync);
 #pragma unroll
             for (int s = 0; s <= NV; ++s) {
                 const cx<T> val = s == NV ? tl : v[s];
@@ -633,7 +646,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
                     if (s == NV) tl = val;
                     else v[s] = val;
                 }
-                run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, p.tw, sync);
+                run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw_core, sync);
                 sync.wave();
 #pragma unroll
                 for (int nb = 0; nb < IL::NB; ++nb) {

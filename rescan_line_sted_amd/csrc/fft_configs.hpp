@@ -165,6 +165,8 @@ struct OuterCol {
     static constexpr int M = 2, C = 8, MIN_WAVES = 1;
     static constexpr bool SPLIT = false;                 // the split pass (COL_SPLIT_*) is what multi-view f32 plans run
     static constexpr int PARK = 0;                       // waiting core results per lane the whole pass keeps in LDS (colconv_outer_body)
+    static constexpr int TWLDS = 0;                      // the whole pass reads the core's (1) and the outer (2) twiddles from an LDS copy
+    static constexpr int TWLDS_SPLIT = 0;                // the same for the halves of the split pass
 };
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
@@ -189,9 +191,19 @@ struct OuterCol<2304> {
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
     static constexpr bool SPLIT = true;    // 2048^2: 4 views 215 -> 236-244 frames/s, 2 views 407 -> 414
 #ifndef RL_PARK_2304
-#define RL_PARK_2304 7
+#define RL_PARK_2304 3
 #endif
-    static constexpr int PARK = RL_PARK_2304;   // 7 values x 512 threads = 28.7 KB beside the 51.3 KB of transforms: two workgroups per CU still fit
+#ifndef RL_TWLDS_SPLIT_2304
+#define RL_TWLDS_SPLIT_2304 1
+#endif
+#ifndef RL_TWLDS_2304
+#define RL_TWLDS_2304 1
+#endif
+    // two workgroups per CU leave 28.7 KB each beside the transforms: the core's twiddles (15.8 KB) + 3 parked values (12.3 KB).
+    // Measured on one box, 2048^2 point: PARK 7 / no copy 664-688 frames/s, copy + PARK 3 766, copy + PARK 0 760
+    static constexpr int TWLDS = RL_TWLDS_2304;
+    static constexpr int TWLDS_SPLIT = RL_TWLDS_SPLIT_2304;   // 2 x (51.3 + 15.8) KB; with the outer table 2 x 80.9 KB would not fit
+    static constexpr int PARK = RL_PARK_2304;
 };
 // 1152 = 2 x 576 (round 3, for the split pass of multi-view plans; as a whole-pass kernel it measured 1.32 -> 1.14 us alone and
 // no gain in the 1024^2 single-view loop in round 2)
@@ -210,6 +222,11 @@ struct OuterCol<1152> {
     // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -
     static constexpr bool SPLIT = false;
     static constexpr int PARK = 0;   // (2 x 10 values per lane: nothing spills)
+#ifndef RL_TWLDS_1152
+#define RL_TWLDS_1152 2
+#endif
+    static constexpr int TWLDS = RL_TWLDS_1152;   // 2 x (51.3 + 15.8 + 4.5) KB
+    static constexpr int TWLDS_SPLIT = 0;
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
@@ -224,9 +241,17 @@ struct OuterCol<4608> {
     static constexpr int M = 8, C = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
     static constexpr bool SPLIT = true;    // 4096^2, 4 views: 33.5 -> 45 frames/s
 #ifndef RL_PARK_4608
-#define RL_PARK_4608 20
+#define RL_PARK_4608 10
 #endif
-    static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 82 KB of parking space beside 51.3 KB
+#ifndef RL_TWLDS_4608
+#define RL_TWLDS_4608 2
+#endif
+    static constexpr int TWLDS = RL_TWLDS_4608;   // + 15.8 KB (core) + 31.5 KB (outer)
+#ifndef RL_TWLDS_SPLIT_4608
+#define RL_TWLDS_SPLIT_4608 2
+#endif
+    static constexpr int TWLDS_SPLIT = RL_TWLDS_SPLIT_4608;
+    static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 41 KB of parking space beside 51.3 KB (10 values are enough for no scratch)
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

@@ -107,6 +107,11 @@ __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && M
 // ---- long column transforms on the wave-private core (conv_kernels.hpp colconv_outer_body) ----
 // L = 2304 = 4 x 576 and 4608 = 8 x 576, f32: fft_configs.hpp OuterCol<L>.  The f64 kernels of these lengths stay
 // the workgroup-synchronous ones (4 x 9 complex doubles per lane would not fit the register file).
+// complex LDS entries of the twiddle copy (conv_kernels.hpp colconv_outer_body TWLDS)
+template <class OC>
+constexpr size_t outer_tw_lds_elems(int twlds) {
+    return (twlds > 0 ? PassTw<typename OC::Core, false, 0>::TOTAL : 0) + (twlds > 1 ? (OC::M - 1) * OC::Core::L : 0);
+}
 template <int L, int C, bool REALP, int MODE = COL_PER_IMAGE>
 __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -127,7 +132,7 @@ __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_oute
             by = w / gx;
         }
     }
-    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE, (MODE == COL_PER_IMAGE ? OC::PARK : 0)>(p, (int)threadIdx.x, (int)bx, (int)by,
+    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE, (MODE == COL_PER_IMAGE ? OC::PARK : 0), (MODE == COL_PER_IMAGE ? OC::TWLDS : OC::TWLDS_SPLIT)>(p, (int)threadIdx.x, (int)bx, (int)by,
                                                                                                              reinterpret_cast<cx<float>*>(smem), s);
 }
 template <int L>
@@ -273,22 +278,23 @@ static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigne
             const ColParams<float>& p = *static_cast<const ColParams<float>*>(params);
             constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
             const dim3 grid((unsigned)((p.kx + OC::C - 1) / OC::C), gy), block(64 * OC::C);
+            constexpr size_t lds_split = lds + outer_tw_lds_elems<OC>(OC::TWLDS_SPLIT) * sizeof(cx<float>);
             if (p.mode == COL_SPLIT_FWD) {
-                rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, grid, block, lds, s, p);
+                rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, grid, block, lds_split, s, p);
                 return hipGetLastError();
             }
             if (p.mode == COL_SPLIT_INV) {
-                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, grid, block, lds, s, p);
-                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, grid, block, lds, s, p);
+                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, grid, block, lds_split, s, p);
+                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, grid, block, lds_split, s, p);
                 return hipGetLastError();
             }
             if (p.mode == COL_SPLIT_INV_SUM) {
-                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, grid, block, lds, s, p);
-                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, grid, block, lds, s, p);
+                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, grid, block, lds_split, s, p);
+                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, grid, block, lds_split, s, p);
                 return hipGetLastError();
             }
             if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
-            constexpr size_t lds_whole = lds + (size_t)OC::PARK * 64 * OC::C * sizeof(cx<float>);   // + the parking space
+            constexpr size_t lds_whole = lds + ((size_t)OC::PARK * 64 * OC::C + outer_tw_lds_elems<OC>(OC::TWLDS)) * sizeof(cx<float>);   // + parking space, twiddles
             if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds_whole, s, p);
             else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false>, grid, block, lds_whole, s, p);
             return hipGetLastError();
@@ -353,15 +359,16 @@ static hipError_t prepare() {
     if constexpr (OuterCol<RL_CFG_L>::value) {
         using OC = OuterCol<RL_CFG_L>;
         constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
-        constexpr size_t lds_whole = lds + (size_t)OC::PARK * 64 * OC::C * sizeof(cx<float>);
+        constexpr size_t lds_whole = lds + ((size_t)OC::PARK * 64 * OC::C + outer_tw_lds_elems<OC>(OC::TWLDS)) * sizeof(cx<float>);
         static_assert(lds_whole <= 160 * 1024, "LDS of a CU");
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds_whole)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds_whole)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, lds)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, lds)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, lds)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, lds)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, lds)) != hipSuccess) return e;
+        constexpr size_t lds_split = lds + outer_tw_lds_elems<OC>(OC::TWLDS_SPLIT) * sizeof(cx<float>);
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, lds_split)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, lds_split)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, lds_split)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, lds_split)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, lds_split)) != hipSuccess) return e;
     }
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;

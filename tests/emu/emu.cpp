@@ -237,13 +237,15 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
     p.tw = tw.data();
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
     p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
-    if (g_park) {   // the device's choices: 7 of the 4 x 10 values (L = 2304), 20 of the 8 x 10 (L = 4608); M = 2: 5
-        constexpr int PARK = M == 4 ? 7 : M == 8 ? 20 : 5;
-        run_grid((kx + C - 1) / C, p.images, 64 * C, ((size_t)C * LdsSlots<Core>::value + (size_t)PARK * 64 * C) * sizeof(cx<T>),
+    if (g_park) {   // the device's choices: 3 of the 4 x 10 values (L = 2304), 10 of the 8 x 10 (L = 4608); M = 2: 5 (for the test)
+        constexpr int PARK = M == 4 ? 3 : M == 8 ? 10 : 5;
+        constexpr int TWLDS = M == 8 ? 2 : 1;     // the twiddles from an LDS copy (L = 4608: the outer table too)
+        run_grid((kx + C - 1) / C, p.images, 64 * C,
+                 ((size_t)C * LdsSlots<Core>::value + (size_t)PARK * 64 * C + (TWLDS > 0 ? PassTw<Core, false, 0>::TOTAL : 0) + (TWLDS > 1 ? (M - 1) * Core::L : 0)) * sizeof(cx<T>),
                  [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                      cx<T>* l = reinterpret_cast<cx<T>*>(lds);
-                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_PER_IMAGE, PARK>(p, tid, bx, by, l, s);
-                     else colconv_outer_body<Core, M, C, T, false, COL_PER_IMAGE, PARK>(p, tid, bx, by, l, s);
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_PER_IMAGE, PARK, TWLDS>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_PER_IMAGE, PARK, TWLDS>(p, tid, bx, by, l, s);
                  });
         return 0;
     }
@@ -285,21 +287,23 @@ static int col_outer_split_t(const T* in, T* out, const T* psf_hat, int real_psf
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = 1; p.in_sv = 0; p.order = 1;
     p.xs_out = xs.data();
     p.xs_in = xs.data();
+    constexpr int TWS = M == 8 ? 2 : M == 4 ? 1 : 0;      // the device's OuterCol<L>::TWLDS_SPLIT
+    constexpr size_t lds_split = ((size_t)C * LdsSlots<Core>::value + (TWS > 0 ? PassTw<Core, false, 0>::TOTAL : 0) + (TWS > 1 ? (M - 1) * Core::L : 0)) * sizeof(cx<T>);
     p.mode = COL_SPLIT_FWD; p.images = n_in;
-    run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
+    run_grid((kx + C - 1) / C, p.images, 64 * C, lds_split,
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
-                 colconv_outer_body<Core, M, C, T, false, COL_SPLIT_FWD>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                 colconv_outer_body<Core, M, C, T, false, COL_SPLIT_FWD, 0, TWS>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
              });
     p.mode = sum_views ? COL_SPLIT_INV_SUM : COL_SPLIT_INV; p.images = sum_views ? frames : frames * V;
-    run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),
+    run_grid((kx + C - 1) / C, p.images, 64 * C, lds_split,
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
                  cx<T>* l = reinterpret_cast<cx<T>*>(lds);
                  if (sum_views) {
-                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_SPLIT_INV_SUM>(p, tid, bx, by, l, s);
-                     else colconv_outer_body<Core, M, C, T, false, COL_SPLIT_INV_SUM>(p, tid, bx, by, l, s);
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_SPLIT_INV_SUM, 0, TWS>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_SPLIT_INV_SUM, 0, TWS>(p, tid, bx, by, l, s);
                  } else {
-                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_SPLIT_INV>(p, tid, bx, by, l, s);
-                     else colconv_outer_body<Core, M, C, T, false, COL_SPLIT_INV>(p, tid, bx, by, l, s);
+                     if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_SPLIT_INV, 0, TWS>(p, tid, bx, by, l, s);
+                     else colconv_outer_body<Core, M, C, T, false, COL_SPLIT_INV, 0, TWS>(p, tid, bx, by, l, s);
                  }
              });
     return 0;

@@ -360,8 +360,8 @@ def test_ratio_minus_one_l576_f32(emu):
 def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf, park):
     """colconv_outer_body: L = M * Li as M core transforms plus one radix-M step in registers (the f32
     column kernel of L = 1152 = 2 x 576, 2304 = 4 x 576 and 4608 = 8 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat),
-    rows < ny.  park: some of the waiting core results per lane wait in LDS instead of registers (PARK: 7 of 4 x 10 used in place
-    during the radix-4 steps, 20 of 8 x 10 brought back for them) -- the same values either way."""
+    rows < ny.  park: some of the waiting core results per lane wait in LDS instead of registers (PARK: 3 of 4 x 10 used in place
+    during the radix-4 steps, 10 of 8 x 10 brought back for them) and the twiddles are read from an LDS copy -- the same values either way."""
     emu.emu_set_park.argtypes = [ctypes.c_int]
     L, V, frames = M * Li, 2, 1
     pitch = (kx + 7) // 8 * 8
