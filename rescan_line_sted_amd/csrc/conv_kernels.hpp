@@ -211,6 +211,8 @@ enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
 
 // MODE is a compile-time parameter: each mode is its own kernel, so the single-view path
 // does not inherit the register footprint of the multi-view loops.
+// (A twiddle copy in LDS like colconv_outer_body's was tried for the fused multi-view modes -- two workgroups per CU, room for it:
+// 512^2 x 4 views 5941 -> 5973 frames/s, noise.  These kernels wait for the vector ALU, not for L1.)
 template <class Cfg, int C, int MODE, typename T, bool REALP = false, class Sync>
 RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
