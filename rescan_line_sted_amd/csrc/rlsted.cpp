@@ -709,7 +709,8 @@ struct rl_deconv {
         // this layout's -- the simulation then stays in spec_b, in place)
         void* sa = !pair ? off(spec_a, (size_t)f0 * n_spec() * 2) : sb;
         RL_TRY(row(ROW_FWD, (unsigned)nf, nullptr, sa, off(obj, (size_t)f0 * n_img()), nullptr, nullptr));
-        RL_TRY(col(sa, sb, nf, true));
+        if (col_split()) RL_TRY(col_split_pass(sa, sb, off(spec_x, (size_t)f0 * V * n_spec_x() * 2), nf, COL_H));   // (the same values as the whole pass)
+        else RL_TRY(col(sa, sb, nf, true));
         RL_TRY(row(ROW_INV, (unsigned)(nf * V), sb, nullptr, nullptr, off(noiseless, (size_t)f0 * V * n_img()), nullptr));
         return RL_OK;
     }

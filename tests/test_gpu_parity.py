@@ -317,10 +317,10 @@ def test_split_column_pass_against_whole_pass(lib, golden, ny, nx, B, monkeypatc
     spectra in register-slot order; COL_SPLIT_INV per view for H, COL_SPLIT_INV_SUM for H_t): against the route through
     the whole per-image kernel and the pre-summed update (RLSTED_COL_SPLIT=0).  H_t sums the views' products before the
     inverse column transform instead of the views' spectra before the inverse row transform: the estimates agree to f32
-    rounding (the simulation -- one whole-kernel H per cycle -- is the same code either way)."""
+    rounding; H is the same arithmetic in the same order either way (bit-identical noiseless images)."""
     psfs = [p[None] for p in golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][:3, 0]]
     obj = np.random.default_rng(ny + nx).random((B, ny, nx)) * 255
-    est = {}
+    est, sim = {}, {}
     for flag in ('0', '1'):
         monkeypatch.setenv('RLSTED_COL_SPLIT', flag)
         plan = lib.DeconvPlan(psfs, B, ny, nx, dtype='f32')
@@ -328,10 +328,12 @@ def test_split_column_pass_against_whole_pass(lib, golden, ny, nx, B, monkeypatc
         assert plan.strategy()['split_column_pass'] == (flag == '1')
         plan.set_object(obj, 5e10 * ny * nx / 128 ** 2)
         plan.simulate(seed=9)
+        sim[flag] = plan.noiseless()
         plan.iterate(3)
         est[flag] = plan.estimate()
         del plan
     monkeypatch.delenv('RLSTED_COL_SPLIT', raising=False)
+    assert np.array_equal(sim['0'], sim['1'])
     assert np.isfinite(est['1']).all() and max_rel(est['1'], est['0']) < 2e-6
 
 
