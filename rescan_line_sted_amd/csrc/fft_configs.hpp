@@ -210,6 +210,9 @@ struct OuterCol<2304> {
 #ifndef RL_OUTER_1152
 #define RL_OUTER_1152 1
 #endif
+#ifndef RL_SPLIT_1152
+#define RL_SPLIT_1152 0
+#endif
 #ifndef RL_OUTER_1152_MIN_WAVES
 #define RL_OUTER_1152_MIN_WAVES 4      // (6 = three workgroups per CU at 80 registers + 48 bytes of scratch: 1024^2 x 4 views 1025 -> 890 frames/s)
 #endif
@@ -219,14 +222,15 @@ struct OuterCol<1152> {
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 2, C = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
     // measured at 1024^2 (frames/s; (8,9,16) x 144 workgroup-synchronous kernel / this body per image / its split pass):
-    // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -
-    static constexpr bool SPLIT = false;
+    // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -;
+    // with the twiddle copies in LDS: 4 views 1078 per image / 993 split, 2 views 1966 / 1650 (RL_SPLIT_1152)
+    static constexpr bool SPLIT = RL_SPLIT_1152 != 0;
     static constexpr int PARK = 0;   // (2 x 10 values per lane: nothing spills)
 #ifndef RL_TWLDS_1152
 #define RL_TWLDS_1152 2
 #endif
     static constexpr int TWLDS = RL_TWLDS_1152;   // 2 x (51.3 + 15.8 + 4.5) KB
-    static constexpr int TWLDS_SPLIT = 0;
+    static constexpr int TWLDS_SPLIT = 2;
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
