@@ -83,6 +83,25 @@ def test_time_cycle_brackets_every_launch(lib, small):
     assert np.array_equal(a, plan.estimate())
 
 
+def test_time_cycle_counts_a_split_column_pass_once(lib, golden):
+    """A multi-view f32 plan on a long column transform: every column pass is two launches (forward half, inverse half);
+    the timing API reports them as ONE pass -- count of passes, sum of both launches' durations."""
+    psfs = [p[None] for p in golden('g8_fig2_psfs')['2p0x_lr/line_sted_psfs'][:3, 0]]
+    B, ny, nx, K = 2, 1200, 96, 3
+    plan = lib.DeconvPlan(psfs, B, ny, nx, dtype='f32')
+    assert plan.info()['ly'] == 2304 and plan.strategy()['split_column_pass']
+    plan.set_object(np.random.default_rng(0).random((B, ny, nx)) * 100, 5e10)
+    kt, fpl = plan.time_cycle(K, seed=1)
+    slices = kt['poisson'][1]
+    assert kt['colconv_H'][1] == K * slices and kt['colconv_Ht'][1] == K * slices     # simulation + iterations 2..K; K x H_t
+    assert kt['colconv_H'][0] > 0 and kt['colconv_Ht'][0] > 0
+    a = plan.estimate()
+    plan.bench_cycles(K, 1, seed=1)
+    assert np.array_equal(a, plan.estimate())
+    alone = plan.time_kernels(2)          # (works on the plan's buffers: the estimate is not kept)
+    assert all(alone[k] > 0 for k in ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE')), alone
+
+
 def test_more_images_than_grid_y(lib):
     rng = np.random.default_rng(0)
     psf = [rng.random((1, 5, 5))]
