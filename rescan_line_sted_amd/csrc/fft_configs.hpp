@@ -162,7 +162,7 @@ template <int L>
 struct OuterCol {
     static constexpr bool value = false;
     using Core = typename CfgFor<64>::Cfg;   // unused
-    static constexpr int M = 2, C = 8, MIN_WAVES = 1;
+    static constexpr int M = 2, C = 8, CW = 8, MIN_WAVES = 1;   // CW: columns per workgroup of the whole pass (C: of the split pass)
     static constexpr bool SPLIT = false;                 // the split pass (COL_SPLIT_*) is what multi-view f32 plans run
     static constexpr int PARK = 0;                       // waiting core results per lane the whole pass keeps in LDS (colconv_outer_body)
     static constexpr int TWLDS = 0;                      // the whole pass reads the core's (1) and the outer (2) twiddles from an LDS copy
@@ -189,6 +189,14 @@ struct OuterCol<2304> {
     static constexpr bool value = RL_OUTER_2304 != 0;
     using Core = typename CfgFor<576>::Cfg;
     static constexpr int M = 4, C = RL_OUTER_C, MIN_WAVES = RL_OUTER_MIN_WAVES;   // waves per SIMD the register budget is cut for
+#ifndef RL_OUTER_CW_2304
+#define RL_OUTER_CW_2304 16
+#endif
+    // The whole pass (single-view plans) on 16-column tiles: whole 128-byte lines, ONE 16-wave workgroup per CU -- and then both
+    // twiddle tables fit beside the transforms (102.6 + 15.8 + 13.5 + 24.6 KB of parking space).  Measured, 2048^2 point, one box:
+    // 8 columns / core table 741 frames/s, 16 / core table 745, 16 / both tables 771.  The split pass stays on 8 columns
+    // (2048^2 x 4 views 248 against 239-247, x 2 views 425 against 404-417).
+    static constexpr int CW = RL_OUTER_CW_2304;
     static constexpr bool SPLIT = true;    // 2048^2: 4 views 215 -> 236-244 frames/s, 2 views 407 -> 414
 #ifndef RL_PARK_2304
 #define RL_PARK_2304 3
@@ -197,10 +205,10 @@ struct OuterCol<2304> {
 #define RL_TWLDS_SPLIT_2304 1
 #endif
 #ifndef RL_TWLDS_2304
-#define RL_TWLDS_2304 1
+#define RL_TWLDS_2304 2
 #endif
-    // two workgroups per CU leave 28.7 KB each beside the transforms: the core's twiddles (15.8 KB) + 3 parked values (12.3 KB).
-    // Measured on one box, 2048^2 point: PARK 7 / no copy 664-688 frames/s, copy + PARK 3 766, copy + PARK 0 760
+    // (history, 8-column tiles at two workgroups per CU: 28.7 KB each beside the transforms -- 7 parked values and no copy 664-688
+    // frames/s at 2048^2 point, the core's table + 3 parked values 766, the table alone 760)
     static constexpr int TWLDS = RL_TWLDS_2304;
     static constexpr int TWLDS_SPLIT = RL_TWLDS_SPLIT_2304;   // 2 x (51.3 + 15.8) KB; with the outer table 2 x 80.9 KB would not fit
     static constexpr int PARK = RL_PARK_2304;
@@ -220,7 +228,7 @@ template <>
 struct OuterCol<1152> {
     static constexpr bool value = RL_OUTER_1152 != 0;
     using Core = typename CfgFor<576>::Cfg;
-    static constexpr int M = 2, C = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
+    static constexpr int M = 2, C = 8, CW = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
     // measured at 1024^2 (frames/s; (8,9,16) x 144 workgroup-synchronous kernel / this body per image / its split pass):
     // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -;
     // with the twiddle copies in LDS: 4 views 1078 per image / 993 split, 2 views 1966 / 1650 (RL_SPLIT_1152)
@@ -242,7 +250,7 @@ template <>
 struct OuterCol<4608> {
     static constexpr bool value = RL_OUTER_4608 != 0;
     using Core = typename CfgFor<576>::Cfg;
-    static constexpr int M = 8, C = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
+    static constexpr int M = 8, C = 8, CW = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
     static constexpr bool SPLIT = true;    // 4096^2, 4 views: 33.5 -> 45 frames/s
 #ifndef RL_PARK_4608
 #define RL_PARK_4608 10

@@ -112,6 +112,10 @@ template <class OC>
 constexpr size_t outer_tw_lds_elems(int twlds) {
     return (twlds > 0 ? PassTw<typename OC::Core, false, 0>::TOTAL : 0) + (twlds > 1 ? (OC::M - 1) * OC::Core::L : 0);
 }
+template <class OC>
+constexpr size_t outer_whole_lds_bytes() {
+    return ((size_t)OC::CW * LdsSlots<typename OC::Core>::value + (size_t)OC::PARK * 64 * OC::CW + outer_tw_lds_elems<OC>(OC::TWLDS)) * sizeof(cx<float>);
+}
 template <int L, int C, bool REALP, int MODE = COL_PER_IMAGE>
 __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -294,9 +298,11 @@ static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigne
                 return hipGetLastError();
             }
             if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
-            constexpr size_t lds_whole = lds + ((size_t)OC::PARK * 64 * OC::C + outer_tw_lds_elems<OC>(OC::TWLDS)) * sizeof(cx<float>);   // + parking space, twiddles
-            if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true>, grid, block, lds_whole, s, p);
-            else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false>, grid, block, lds_whole, s, p);
+            // the whole pass has a tile width of its own (OC::CW), its transform regions + parking space + twiddle copies
+            constexpr size_t lds_whole = outer_whole_lds_bytes<OC>();
+            const dim3 grid_w((unsigned)((p.kx + OC::CW - 1) / OC::CW), gy), block_w(64 * OC::CW);
+            if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::CW, true>, grid_w, block_w, lds_whole, s, p);
+            else rl_launch(k_colconv_outer<RL_CFG_L, OC::CW, false>, grid_w, block_w, lds_whole, s, p);
             return hipGetLastError();
         }
     }
@@ -359,10 +365,10 @@ static hipError_t prepare() {
     if constexpr (OuterCol<RL_CFG_L>::value) {
         using OC = OuterCol<RL_CFG_L>;
         constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
-        constexpr size_t lds_whole = lds + ((size_t)OC::PARK * 64 * OC::C + outer_tw_lds_elems<OC>(OC::TWLDS)) * sizeof(cx<float>);
+        constexpr size_t lds_whole = outer_whole_lds_bytes<OC>();
         static_assert(lds_whole <= 160 * 1024, "LDS of a CU");
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true>, lds_whole)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false>, lds_whole)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::CW, true>, lds_whole)) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::CW, false>, lds_whole)) != hipSuccess) return e;
         constexpr size_t lds_split = lds + outer_tw_lds_elems<OC>(OC::TWLDS_SPLIT) * sizeof(cx<float>);
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, lds_split)) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, lds_split)) != hipSuccess) return e;
