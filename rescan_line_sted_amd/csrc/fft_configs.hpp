@@ -218,6 +218,9 @@ struct OuterCol<2304> {
 #ifndef RL_OUTER_1152
 #define RL_OUTER_1152 1
 #endif
+#ifndef RL_OUTER_CW_1152
+#define RL_OUTER_CW_1152 8      // (16: 1024^2 x 4 views 1084 -> 1030 frames/s, point 3900 -> 3820)
+#endif
 #ifndef RL_SPLIT_1152
 #define RL_SPLIT_1152 0
 #endif
@@ -228,7 +231,7 @@ template <>
 struct OuterCol<1152> {
     static constexpr bool value = RL_OUTER_1152 != 0;
     using Core = typename CfgFor<576>::Cfg;
-    static constexpr int M = 2, C = 8, CW = 8, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
+    static constexpr int M = 2, C = 8, CW = RL_OUTER_CW_1152, MIN_WAVES = RL_OUTER_1152_MIN_WAVES;
     // measured at 1024^2 (frames/s; (8,9,16) x 144 workgroup-synchronous kernel / this body per image / its split pass):
     // 4 views 705 / 1015-1043 / 995-1027, 2 views - / 1900 / 1690-1740, 1 view (frame pairs) - / 3820-3850 / -;
     // with the twiddle copies in LDS: 4 views 1078 per image / 993 split, 2 views 1966 / 1650 (RL_SPLIT_1152)
