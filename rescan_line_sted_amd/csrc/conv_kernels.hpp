@@ -590,9 +590,10 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
         cx<T>* __restrict__ const park = lds + C * LP + tid;       // value e of this thread at park[e * NT]
         Regs Y;
         // forward: as forward_classes(), a finished class goes to the parking space while the later ones are transformed
-        // One workgroup per CU (M = 8): the next class's rows are requested before this one is transformed (4096^2 K = 100
-        // 34.6 -> 35.9 frames/s).  With two workgroups per CU (M = 4) the other workgroup fills the wait: 770 -> 759 at 2048^2, not used.
-        constexpr bool PREFETCH = M >= 8;
+        // One workgroup per CU (M = 8, and M = 4 on 16-column tiles): the next class's rows are requested before this one is
+        // transformed (4096^2 K = 100 34.6 -> 35.9 frames/s; 2048^2 801 -> 811).  With two workgroups per CU the other workgroup
+        // fills the wait (M = 4 on 8-column tiles: 770 -> 759).
+        constexpr bool PREFETCH = M >= 8 || C >= 16;
         cx<T> x[NLD];
         if constexpr (PREFETCH) fetch_class(in, 0, x);
 #pragma unroll
