@@ -131,6 +131,31 @@ def test_multi_view_long_transforms_f32_vs_f64_plan(lib, golden, ny, nx, views):
     assert err < F32_MARGIN, err
 
 
+@pytest.mark.parametrize('ny,nx,B', [(2048, 100, 2), (1500, 33, 3), (4096, 40, 2), (1100, 1100, 1), (700, 2048, 2)])
+def test_single_view_long_columns_odd_shapes(lib, golden, ny, nx, B, monkeypatch):
+    """The whole column pass of the long transforms (16-column tiles at L = 2304, twiddle copies and parked values in LDS, the next
+    residue class prefetched) on shapes whose spectra do not fill whole tiles: tall and narrow images, a single frame (no pair),
+    an odd batch (half-empty last pair); f32 against the f64 plan, pair loop and per-frame loop."""
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    obj = np.random.default_rng(ny + nx).random((B, ny, nx)) * 255
+    p64 = lib.DeconvPlan(psf, B, ny, nx, dtype='f64')
+    p64.set_object(obj, 5e10 * ny * nx / 128 ** 2)
+    p64.simulate(seed=4)
+    noisy = p64.measurement()
+    p64.iterate(10)
+    ref = p64.estimate()
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RLSTED_PAIR', flag)
+        p32 = lib.DeconvPlan(psf, B, ny, nx, dtype='f32')
+        p32.set_object(obj, 5e10 * ny * nx / 128 ** 2)
+        p32.set_measurement(noisy)
+        p32.iterate(10)
+        err = max(max_rel(p32.estimate()[b], ref[b]) for b in range(B))
+        assert err < F32_MARGIN, (flag, err)
+        del p32
+    monkeypatch.delenv('RLSTED_PAIR', raising=False)
+
+
 @pytest.mark.parametrize('size', [2048, 4096])
 def test_frame_pairs_on_the_long_transforms(lib, golden, size, monkeypatch):
     """L = 2304 / 4608 (one workgroup-synchronous row transform per workgroup): the frame-pair loop (the default for f32
