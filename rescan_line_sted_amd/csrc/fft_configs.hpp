@@ -83,13 +83,19 @@ struct CfgFor<2304> { // 2048 + 53
 #ifndef RL_2304_Q32
 #define RL_2304_Q32 1   // one row pair per workgroup: 7 workgroups per CU overlap their phases (+9 % at 2048^2 over 2)
 #endif
-    static constexpr int C32 = RL_2304_C32, C64 = 2, Q32 = RL_2304_Q32, Q64 = 1;
+#ifndef RL_2304_C64
+#define RL_2304_C64 3      // f64 column tiles: 2 / 3 columns 225 / 252 frames/s at 2048^2 (4 do not fit the LDS)
+#endif
+    static constexpr int C32 = RL_2304_C32, C64 = RL_2304_C64, Q32 = RL_2304_Q32, Q64 = 1;
 };
 
 template <>
 struct CfgFor<4608> { // 4096 + 53
     using Cfg = FftCfg<4608, 576, 8, 8, 8, 9>;     // row kernels; columns: ColCfgFor<4608> below
-    static constexpr int C32 = 3, C64 = 1, Q32 = 1, Q64 = 1;
+#ifndef RL_4608_C64
+#define RL_4608_C64 2      // f64 column tiles: 1 / 2 columns 35.2 / 46.5 frames/s at 4096^2, K = 20
+#endif
+    static constexpr int C32 = 3, C64 = RL_4608_C64, Q32 = 1, Q64 = 1;
 };
 
 // One pad slot per 16 elements for L = 2304 (RL_2304_PAD_SHIFT): 4 columns then take 78 KB instead
