@@ -584,7 +584,8 @@ struct rl_deconv {
         }
         if (c < 1) c = 1;
         if (c >= B) return B;
-        // equal slices (a short last slice would run its 4 launches per iteration nearly empty)
+        // equal slices (a short last slice would run its 4 launches per iteration nearly empty; slices BALANCED to within one frame --
+        // 6 6 5 5 5 5 instead of 6 6 6 6 6 2 for 32 frames -- measured +1 % at 2048^2 x 4 views and -1 % at 512^2 x 4 views, 250 frames: not done)
         const int fit = c;                       // frames the budget holds
         const int slices = (B + c - 1) / c;
         c = (B + slices - 1) / slices;
