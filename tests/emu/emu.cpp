@@ -214,10 +214,10 @@ int emu_row_pair_f32(int L, int mode, const float* spec_in, float* spec_out, con
 }  // extern "C"
 // ColParams-independent: waiting core results per lane kept in LDS by the whole pass (conv_kernels.hpp PARK); 0 = none
 static int g_park = 0;
-template <class Core, int M, typename T>
+template <class Core, int M, typename T, int C = 8>
 static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int ny, int kx, int pitch, int V, int frames,
                        int in_sb, int in_sv, int mode = COL_PER_IMAGE) {
-    constexpr int C = 8, L = M * Core::L;
+    constexpr int L = M * Core::L;
     constexpr int n_core = PassTw<Core, false, 0>::TOTAL;
     std::vector<double> h(2 * (size_t)(n_core + (M - 1) * Core::L));
     fill_pass_twiddles<Core>(h.data());
@@ -239,7 +239,7 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
     p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
     if (g_park) {   // the device's choices: 3 of the 4 x 10 values (L = 2304), 10 of the 8 x 10 (L = 4608); M = 2: 5 (for the test)
         constexpr int PARK = M == 4 ? 3 : M == 8 ? 10 : 5;
-        constexpr int TWLDS = M == 8 ? 2 : 1;     // the twiddles from an LDS copy (L = 4608: the outer table too)
+        constexpr int TWLDS = (M == 8 || C == 16) ? 2 : 1;     // the twiddles from an LDS copy (L = 4608 and the 16-column tiles of 2304: the outer table too)
         run_grid((kx + C - 1) / C, p.images, 64 * C,
                  ((size_t)C * LdsSlots<Core>::value + (size_t)PARK * 64 * C + (TWLDS > 0 ? PassTw<Core, false, 0>::TOTAL : 0) + (TWLDS > 1 ? (M - 1) * Core::L : 0)) * sizeof(cx<T>),
                  [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
@@ -352,6 +352,7 @@ int emu_col_outer_f64(int Li, int M, const double* in, double* out, const double
     using C256 = CfgFor<256>::Cfg;
     using C576 = CfgFor<576>::Cfg;
     if (Li == 256 && M == 4) return col_outer_t<C256, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
+    if (Li == 256 && M == 16) return col_outer_t<C256, 4, double, 16>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);   // M = 4 on 16-column tiles
     if (Li == 256 && M == 2) return col_outer_t<C256, 2, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     if (Li == 576 && M == 4) return col_outer_t<C576, 4, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
     if (Li == 256 && M == 8) return col_outer_t<C256, 8, double>(in, out, psf_hat, real_psf, ny, kx, pitch, V, frames, in_sb, in_sv);
