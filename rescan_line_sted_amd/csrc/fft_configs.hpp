@@ -225,7 +225,8 @@ struct OuterCol<2304> {
 #define RL_OUTER_1152 1
 #endif
 #ifndef RL_OUTER_CW_1152
-#define RL_OUTER_CW_1152 8      // (16: 1024^2 x 4 views 1084 -> 1030 frames/s, point 3900 -> 3820)
+#define RL_OUTER_CW_1152 8      // (16: 1024^2 x 4 views 1084 -> 1030 frames/s, point 3900 -> 3820; 9 -- 128 tiles per pair spectrum,
+                                // a 4-pair launch exactly one round of workgroups -- 897 / 3560; 12: 972 / 3758: unaligned segments cost more)
 #endif
 #ifndef RL_SPLIT_1152
 #define RL_SPLIT_1152 0
