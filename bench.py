@@ -518,8 +518,8 @@ def main():
                  'three RL kernels 80-90 % VALU-active when they run alone: fp32 vector issue, not memory, is what the path waits for '
                  '(DESIGN.md section 4)') if size < 1024 else
                 ('priced against the HBM roofline as BASELINE.json asks; at this size the slices stream through HBM and every kernel of '
-                 'the iteration runs at 3.1-4.4 TB/s of fabric traffic alone (profiles/r03/split_2048, point_2048_head): the loop is at '
-                 'the rate this part sustains for its bytes, which are ~2-3x the image-sized passes because every spectrum crosses '
+                 'the iteration runs at 3.1-4.4 TB/s of fabric traffic alone (profiles/r03/split_2048, point_2048_head): a plain copy on this part '
+                 'moves 5.1 TB/s (tools/gpu/gpu_stream_rate.py): the loop is near the streaming rate for its bytes, which are ~2-3x the image-sized passes because every spectrum crosses '
                  'memory between its row and its column pass (DESIGN.md section 3)'),
         'kernel': ('one RL iteration over one slice = 6 launches: split column pass of H (k_colconv_outer<FWD>, <INV>), k_rowpass<RATIO>, '
                    'split column pass of H_t (k_colconv_outer<FWD>, <INV_SUM>), k_rowpass<UPDATE>; colconv_H / colconv_Ht = both halves'
