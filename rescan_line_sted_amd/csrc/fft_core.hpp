@@ -305,6 +305,12 @@ inline void fill_pass_twiddles(double* out) {
     fill_pass_twiddles_one<Cfg, true, 0>(out);
 }
 
+#ifndef RL_COMPACT_TW
+#define RL_COMPACT_TW 1
+#endif
+#ifndef RL_COMPACT_TW_MIN_L
+#define RL_COMPACT_TW_MIN_L 1152
+#endif
 template <class Cfg, bool INV, int P, typename T>
 RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
     using PI = PassInfo<Cfg, INV, P>;
@@ -314,9 +320,29 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
             if constexpr (PI::NS > 1) {
+#if defined(RL_DEBUG_TW0)   // timing study only (wrong results): every lane reads the same twiddles -- what the table's L2 traffic costs
+                const cx<T>* __restrict__ w = tw + PassTw<Cfg, INV, P>::OFFSET + (Cfg::L >= 1152 ? 0 : j);
+#else
                 const cx<T>* __restrict__ w = tw + PassTw<Cfg, INV, P>::OFFSET + j;
+#endif
+                // COMPACT (the long f32 transforms, whose tables -- 69 KB at L = 2304 -- do not stay in L1: 53 of the row kernels'
+                // 79 vector loads are twiddles, 2x the data's bytes out of L2; all lanes reading ONE entry instead measured 2048^2
+                // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the
+                // same table: 4/15 of its lines are ever touched), the others are products of two of those (<= 3 roundings deep)
+                constexpr bool COMPACT = RL_COMPACT_TW != 0 && sizeof(T) == 4 && Cfg::L >= RL_COMPACT_TW_MIN_L && R > 4;
+                if constexpr (COMPACT) {
+                    cx<T> wp[R];
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[nb * R + r] = cmul(v[nb * R + r], w[(r - 1) * PI::NBF]);
+                    for (int r = 1; r < R; ++r) {
+                        int hb = 1;
+                        while (2 * hb <= r) hb *= 2;
+                        wp[r] = r == hb ? w[(r - 1) * PI::NBF] : cmul(wp[hb], wp[r - hb]);
+                        v[nb * R + r] = cmul(v[nb * R + r], wp[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[nb * R + r] = cmul(v[nb * R + r], w[(r - 1) * PI::NBF]);
+                }
             }
             dft<R, INV>(&v[nb * R]);
         }
