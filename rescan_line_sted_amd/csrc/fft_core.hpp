@@ -308,6 +308,9 @@ inline void fill_pass_twiddles(double* out) {
 #ifndef RL_COMPACT_TW
 #define RL_COMPACT_TW 1
 #endif
+#ifndef RL_COMPACT_TW_F64
+#define RL_COMPACT_TW_F64 1      // f64 too (tables twice the size): 2048^2 253 -> 311 frames/s, x 4 views 74 -> 90.5, 4096^2 46.4 -> 53.1
+#endif
 #ifndef RL_COMPACT_TW_MIN_L
 #define RL_COMPACT_TW_MIN_L 1152
 #endif
@@ -329,7 +332,7 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
                 // 79 vector loads are twiddles, 2x the data's bytes out of L2; all lanes reading ONE entry instead measured 2048^2
                 // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the
                 // same table: 4/15 of its lines are ever touched), the others are products of two of those (<= 3 roundings deep)
-                constexpr bool COMPACT = RL_COMPACT_TW != 0 && sizeof(T) == 4 && Cfg::L >= RL_COMPACT_TW_MIN_L && R > 4;
+                constexpr bool COMPACT = RL_COMPACT_TW != 0 && (sizeof(T) == 4 || RL_COMPACT_TW_F64 != 0) && Cfg::L >= RL_COMPACT_TW_MIN_L && R > 4;
                 if constexpr (COMPACT) {
                     cx<T> wp[R];
 #pragma unroll

@@ -1,6 +1,6 @@
 """Manual helper (not a test): whole-cycle throughput of float64 plans (the reference's arithmetic) at the long transform lengths.
-End of round 3: 1024^2 1302, 2048^2 256 (4 views: 74), 4096^2 46.5 frames/s at K = 20 (225 / 72 / 35 before their column tiles went from 2 / 1 to
-3 / 2 columns) -- 3-4x below the f32 plans (2x is the byte ratio):
+End of round 3: 1024^2 1376, 2048^2 311 (4 views: 90), 4096^2 53 frames/s at K = 20 (1302 / 225 / 72 / 35 before their column tiles went from
+2 / 1 to 3 / 2 columns and their twiddles to the compact form) -- ~3x below the f32 plans (2x is the byte ratio):
 the f64 column kernels of L = 1152 ... 4608 are still the workgroup-synchronous ones (4 x 10 complex doubles per lane do not fit the
 outer-decimation body's register budget).
 
