@@ -308,6 +308,9 @@ inline void fill_pass_twiddles(double* out) {
 #ifndef RL_COMPACT_TW
 #define RL_COMPACT_TW 1
 #endif
+#ifndef RL_COMPACT_TW_BASE
+#define RL_COMPACT_TW_BASE 2      // (4 -- only w^1 and w^4 loaded for a radix-16 pass -- measured the same speed: 2 keeps the products shallower)
+#endif
 #ifndef RL_COMPACT_TW_F64
 #define RL_COMPACT_TW_F64 1      // f64 too (tables twice the size): 2048^2 253 -> 311 frames/s, x 4 views 74 -> 90.5, 4096^2 46.4 -> 53.1
 #endif
@@ -338,8 +341,9 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
 #pragma unroll
                     for (int r = 1; r < R; ++r) {
                         int hb = 1;
-                        while (2 * hb <= r) hb *= 2;
-                        wp[r] = r == hb ? w[(r - 1) * PI::NBF] : cmul(wp[hb], wp[r - hb]);
+                        while (RL_COMPACT_TW_BASE * hb <= r) hb *= RL_COMPACT_TW_BASE;     // largest loaded power <= r
+                        const int q = r / hb * hb;                                         // (base 2: q == hb)
+                        wp[r] = r == hb ? w[(r - 1) * PI::NBF] : (q == r ? cmul(wp[q - hb], wp[hb]) : cmul(wp[q], wp[r - q]));
                         v[nb * R + r] = cmul(v[nb * R + r], wp[r]);
                     }
                 } else {
