@@ -308,14 +308,22 @@ inline void fill_pass_twiddles(double* out) {
 #ifndef RL_COMPACT_TW
 #define RL_COMPACT_TW 1
 #endif
+#ifndef RL_COMPACT_TW_DEPTH1
+#define RL_COMPACT_TW_DEPTH1 1     // one product deep (6 of 15 loaded) instead of up to three (4 of 15): the same speed, less rounding
+#endif
 #ifndef RL_COMPACT_TW_BASE
 #define RL_COMPACT_TW_BASE 2      // (4 -- only w^1 and w^4 loaded for a radix-16 pass -- measured the same speed: 2 keeps the products shallower)
 #endif
 #ifndef RL_COMPACT_TW_F64
 #define RL_COMPACT_TW_F64 1      // f64 too (tables twice the size): 2048^2 253 -> 311 frames/s, x 4 views 74 -> 90.5, 4096^2 46.4 -> 53.1
 #endif
+#ifndef RL_COMPACT_TW_MIN_L_F64
+#define RL_COMPACT_TW_MIN_L_F64 576
+#endif
 #ifndef RL_COMPACT_TW_MIN_L
-#define RL_COMPACT_TW_MIN_L 1152
+#define RL_COMPACT_TW_MIN_L 1152     // f32: not the wave-private 576, although it is 3-4 % faster there too (512^2 point 18961 -> 19554 frames/s,
+                                     // three alternating runs each): the pixelwise error of two config-2 cases goes from 2.3e-4 to 3.2e-4
+                                     // (3.8e-4 with the deeper products), past what tests/test_gpu_configs.py asserts.  f64 (below): 9448 -> 9600
 #endif
 template <class Cfg, bool INV, int P, typename T>
 RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
@@ -335,15 +343,22 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
                 // 79 vector loads are twiddles, 2x the data's bytes out of L2; all lanes reading ONE entry instead measured 2048^2
                 // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the
                 // same table: 4/15 of its lines are ever touched), the others are products of two of those (<= 3 roundings deep)
-                constexpr bool COMPACT = RL_COMPACT_TW != 0 && (sizeof(T) == 4 || RL_COMPACT_TW_F64 != 0) && Cfg::L >= RL_COMPACT_TW_MIN_L && R > 4;
+                constexpr bool COMPACT = RL_COMPACT_TW != 0 && (sizeof(T) == 4 || RL_COMPACT_TW_F64 != 0) && R > 4 &&
+                                         Cfg::L >= (sizeof(T) == 4 ? RL_COMPACT_TW_MIN_L : RL_COMPACT_TW_MIN_L_F64);
                 if constexpr (COMPACT) {
                     cx<T> wp[R];
 #pragma unroll
                     for (int r = 1; r < R; ++r) {
+#if RL_COMPACT_TW_DEPTH1
+                        // loaded: r < 4 and the multiples of 4; every other one is ONE product of two loaded values
+                        const bool loaded = r < 4 || r % 4 == 0;
+                        wp[r] = loaded ? w[(r - 1) * PI::NBF] : cmul(wp[r - r % 4], wp[r % 4]);
+#else
                         int hb = 1;
                         while (RL_COMPACT_TW_BASE * hb <= r) hb *= RL_COMPACT_TW_BASE;     // largest loaded power <= r
                         const int q = r / hb * hb;                                         // (base 2: q == hb)
                         wp[r] = r == hb ? w[(r - 1) * PI::NBF] : (q == r ? cmul(wp[q - hb], wp[hb]) : cmul(wp[q], wp[r - q]));
+#endif
                         v[nb * R + r] = cmul(v[nb * R + r], wp[r]);
                     }
                 } else {
