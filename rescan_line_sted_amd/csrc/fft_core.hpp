@@ -317,6 +317,10 @@ inline void fill_pass_twiddles(double* out) {
 #ifndef RL_COMPACT_TW_F64
 #define RL_COMPACT_TW_F64 1      // f64 too (tables twice the size): 2048^2 253 -> 311 frames/s, x 4 views 74 -> 90.5, 4096^2 46.4 -> 53.1
 #endif
+#ifndef RL_COMPACT_TW_SMALL_L
+#define RL_COMPACT_TW_SMALL_L 256     // ... and the short lengths (64, 192, 256: the 128^2 configs): 128^2 point 208 -> 217 k frames/s, x 4 views 62.8 -> 64.7 k,
+                                      // every accuracy test of those sizes unchanged
+#endif
 #ifndef RL_COMPACT_TW_MIN_L_F64
 #define RL_COMPACT_TW_MIN_L_F64 576
 #endif
@@ -344,7 +348,7 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
                 // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the
                 // same table: 4/15 of its lines are ever touched), the others are products of two of those (<= 3 roundings deep)
                 constexpr bool COMPACT = RL_COMPACT_TW != 0 && (sizeof(T) == 4 || RL_COMPACT_TW_F64 != 0) && R > 4 &&
-                                         Cfg::L >= (sizeof(T) == 4 ? RL_COMPACT_TW_MIN_L : RL_COMPACT_TW_MIN_L_F64);
+                                         (Cfg::L >= (sizeof(T) == 4 ? RL_COMPACT_TW_MIN_L : RL_COMPACT_TW_MIN_L_F64) || Cfg::L <= RL_COMPACT_TW_SMALL_L);
                 if constexpr (COMPACT) {
                     cx<T> wp[R];
 #pragma unroll
