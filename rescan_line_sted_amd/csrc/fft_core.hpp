@@ -327,7 +327,8 @@ inline void fill_pass_twiddles(double* out) {
 #ifndef RL_COMPACT_TW_MIN_L
 #define RL_COMPACT_TW_MIN_L 1152     // f32: not the wave-private 576, although it is 3-4 % faster there too (512^2 point 18961 -> 19554 frames/s,
                                      // three alternating runs each): the pixelwise error of two config-2 cases goes from 2.3e-4 to 3.2e-4
-                                     // (3.8e-4 with the deeper products), past what tests/test_gpu_configs.py asserts.  f64 (below): 9448 -> 9600
+                                     // (3.8e-4 with the deeper products; 3.04e-4 and +2 % with only w^5 and w^7 of a radix-8 butterfly as products),
+                                     // past the 3e-4 tests/test_gpu_configs.py asserts.  f64 (below): 9448 -> 9600
 #endif
 template <class Cfg, bool INV, int P, typename T>
 RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
