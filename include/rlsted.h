@@ -170,6 +170,21 @@ typedef struct rl_task {
 } rl_task;
 int rl_batch_run(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, double* estimates_out);
 
+/* The same work, ENQUEUED: returns once the tasks' objects are staged (page-locked buffers of the plan, two chunks deep) and
+ * every copy and kernel is in the context's stream order -- chunk i + 1 is uploaded on a copy stream while chunk i iterates, and
+ * successive calls, on this plan or on other plans of the context, follow each other on the device without the host in
+ * between.  The estimates go to DEVICE memory: dev_out [n_tasks][ny][nx] of out_dtype (RL_F32 / RL_F64; rl_device_alloc, or
+ * any device pointer of this GPU), NULL: nowhere (the last chunk stays in the plan's buffers).  Nothing of the result may be
+ * read, and the plan not destroyed, before rl_ctx_synchronize.  rl_batch_run is this call with a buffer of its own followed by
+ * ONE download.  line_sted_figure_2.py:39-57 is a loop of such runs: one per (PSF set, test image).                       */
+int rl_batch_submit(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, void* dev_out, int out_dtype);
+
+/* Device memory owned by the caller: the result buffer of a sweep (rl_batch_submit), the operands of rl_comm_gather_device.
+ * rl_device_download: n elements of `dtype` -> host float64 (blocking; synchronises the context first).                   */
+int rl_device_alloc(rl_ctx* ctx, size_t bytes, void** dev_out);
+int rl_device_free(rl_ctx* ctx, void* dev);
+int rl_device_download(rl_ctx* ctx, const void* dev, int dtype, size_t n_elements, double* host_out);
+
 /* ---- multi-GPU: one process per GPU, frames sharded over ranks -----------------
  * The reference is single process; independent simulations shard with no
  * data-path collective and ONE gather of the results at the end (section 8e).  RCCL over xGMI,
@@ -191,6 +206,13 @@ int rl_comm_allreduce_max(rl_comm* c, double* value);
  * result in a device buffer owned by the communicator (root: *dev_out, valid until the next
  * rl_gather / rl_gather_device of this communicator -- rl_comm_gather_host stages through a buffer of its own and
  * leaves it alone; other ranks: NULL) in the plan's dtype.                                 */
+/* The sweep's one gather: counts[r] elements of `dtype` from every rank r's DEVICE buffer dev_local, rank-major
+ * into dev_out on the root (device memory of the root's GPU holding sum(counts) elements; ignored elsewhere) -- results of
+ * different shapes travel unpadded, in the plan's own arithmetic type.  Synchronises the device on both sides of the transfer. */
+int rl_comm_gather_device(rl_comm* c, const void* dev_local, const size_t* counts, int dtype, int root, void* dev_out);
+/* n float64 values from `root`'s host buffer into every rank's (the PSF sets of a sweep are built once -- the reference builds
+ * them once per figure, line_sted_figure_2.py:66-72 -- and sent to the other ranks).  Collective.                          */
+int rl_comm_bcast_host(rl_comm* c, double* buf, size_t n, int root);
 int rl_gather(rl_comm* c, rl_deconv* plan, int which, int root, const int* counts, double* host_out);
 int rl_gather_device(rl_comm* c, rl_deconv* plan, int which, int root, const int* counts, void** dev_out,
                      size_t* n_elements, int* dtype);

@@ -65,20 +65,19 @@ def jobs():
 VARIANTS = {   # study builds: librlsted_<name>.so beside the product library (python -m ..._build --variant NAME)
     'q16': ['-DRL_SPEC_QUANT=1'],     # spectra rounded to IEEE half on their way to memory (BASELINE config 5 study)
     'qbf16': ['-DRL_SPEC_QUANT=2'],   # ... to bfloat16
-    'ab1': os.environ.get('RL_AB1', '').split(),   # scratch A/B builds (development): flags from the environment
-    'ab2': os.environ.get('RL_AB2', '').split(),
 }
 
 
-def build_variant(name, verbose=False):
-    """A study build of the whole library with extra defines, objects under build/obj_<name>/."""
+def build_variant(name, verbose=False, flags=None):
+    """A study build of the whole library with extra defines, objects under build/obj_<name>/.  `flags`: an explicit flag
+    list for a development A/B build (tools/ab_build.py); the named study variants above take theirs from VARIANTS."""
     global OBJ, LIB, DEVICE
     keep = (OBJ, LIB, DEVICE)
     try:
         OBJ = os.path.join(ROOT, 'build', 'obj_' + name)
         LIB = os.path.join(LIBDIR, 'librlsted_%s.so' % name)
-        DEVICE = DEVICE + VARIANTS[name]
-        return build(force=name.startswith('ab'), verbose=verbose)   # (the scratch builds' flags change between runs)
+        DEVICE = DEVICE + (VARIANTS[name] if flags is None else list(flags))
+        return build(force=flags is not None, verbose=verbose)   # (a development build's flags change between runs)
     finally:
         OBJ, LIB, DEVICE = keep
 

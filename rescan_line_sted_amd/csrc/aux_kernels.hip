@@ -313,6 +313,19 @@ hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hip
     return hipGetLastError();
 }
 
+template <typename S, typename D>
+__global__ void k_cast(const S* __restrict__ src, D* __restrict__ dst, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) dst[i] = (D)src[i];
+}
+hipError_t aux_cast(int dtype_src, const void* src, int dtype_dst, void* dst, size_t total, hipStream_t s) {
+    if (total == 0) return hipSuccess;
+    if (dtype_src == dtype_dst) return hipMemcpyAsync(dst, src, total * (dtype_src == DT_F32 ? 4 : 8), hipMemcpyDeviceToDevice, s);
+    const unsigned g = blocks_for(total, 256);
+    if (dtype_src == DT_F32) k_cast<float, double><<<g, 256, 0, s>>>((const float*)src, (double*)dst, total);
+    else k_cast<double, float><<<g, 256, 0, s>>>((const double*)src, (float*)dst, total);
+    return hipGetLastError();
+}
+
 size_t aux_poisson_workspace_bytes(size_t total_pixels) {
     const unsigned g = blocks_for(total_pixels, 256);
     const size_t seg_cap = (total_pixels + (size_t)g * 256 - 1) / ((size_t)g * 256) * 256;

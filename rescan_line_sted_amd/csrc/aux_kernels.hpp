@@ -26,6 +26,8 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
                              double* sums, hipStream_t s, bool want_sums = false);
 hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s);
+// dst[i] = (dst type) src[i]: a plan buffer into a result buffer of another arithmetic type (same type: a device copy)
+hipError_t aux_cast(int dtype_src, const void* src, int dtype_dst, void* dst, size_t total, hipStream_t s);
 // re[i] = z[i].re for n complex values of `dtype`; stats (device, 2 doubles) <- max |im|, max(|re|, |im|)
 hipError_t aux_split_real(int dtype, const void* z, size_t n, void* re, double* stats, hipStream_t s);
 // out [ny][nx] (plan dtype) = sum_v max(conv_same(ones, psf_v), 0) from the PSFs' float64 integral images

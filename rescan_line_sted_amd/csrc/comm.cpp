@@ -29,6 +29,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -62,6 +63,7 @@ static void rccl_load(Rccl& r) {
     RL_SYM(Send, "ncclSend")
     RL_SYM(Recv, "ncclRecv")
     RL_SYM(AllReduce, "ncclAllReduce")
+    RL_SYM(Broadcast, "ncclBroadcast")
     RL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RL_SYM
 }
@@ -287,6 +289,68 @@ int rl_comm_gather_host(rl_comm* c, const double* local, const size_t* counts, i
         RCCL_TRY(r->Send(buf, mine, ncclDouble, root, c->comm, s));
         RCCL_TRY(group.end());
     }
+    HIP_TRY(hipStreamSynchronize(s));
+    return RL_OK;
+}
+
+// The sweep's gather: counts[r] elements from rank r's device buffer, rank-major into the root's device buffer -- no padding, no
+// host staging, the plans' own arithmetic type (SURVEY 8e sized config 4's gather at 75 MB of fp32).
+int rl_comm_gather_device(rl_comm* c, const void* dev_local, const size_t* counts, int dtype, int root, void* dev_out) {
+    if (!c || !counts) return fail(RL_ERR_INVALID, "NULL argument");
+    if (root < 0 || root >= c->world) return fail(RL_ERR_INVALID, "no such root rank");
+    if (dtype != RL_F32 && dtype != RL_F64) return fail(RL_ERR_INVALID, "dtype must be RL_F32 or RL_F64");
+    const size_t mine = counts[c->rank], es = dtype == RL_F32 ? 4 : 8;
+    if (mine && !dev_local) return fail(RL_ERR_INVALID, "dev_local is NULL");
+    const ncclDataType_t nt = dtype == RL_F32 ? ncclFloat : ncclDouble;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    hipStream_t s = c->ctx->stream;
+    HIP_TRY(hipDeviceSynchronize());   // whatever produced dev_local, on any stream, has finished
+    Rccl* r = rccl();
+    if (c->rank == root) {
+        size_t total = 0;
+        for (int k = 0; k < c->world; ++k) total += counts[k];
+        if (total && !dev_out) return fail(RL_ERR_INVALID, "dev_out is NULL on the root rank");
+        GroupScope group(r);
+        RCCL_TRY(group.start());
+        size_t off = 0;
+        for (int k = 0; k < c->world; ++k) {
+            char* dst = (char*)dev_out + off * es;
+            if (k == root) {
+                if (mine) HIP_TRY(hipMemcpyAsync(dst, dev_local, mine * es, hipMemcpyDeviceToDevice, s));
+            } else if (counts[k]) {
+                RCCL_TRY(r->Recv(dst, counts[k], nt, k, c->comm, s));
+            }
+            off += counts[k];
+        }
+        RCCL_TRY(group.end());
+    } else if (mine) {
+        GroupScope group(r);
+        RCCL_TRY(group.start());
+        RCCL_TRY(r->Send(dev_local, mine, nt, root, c->comm, s));
+        RCCL_TRY(group.end());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return RL_OK;
+}
+
+int rl_comm_bcast_host(rl_comm* c, double* buf, size_t n, int root) {
+    if (!c || (n && !buf)) return fail(RL_ERR_INVALID, "NULL argument");
+    if (root < 0 || root >= c->world) return fail(RL_ERR_INVALID, "no such root rank");
+    if (n == 0) return RL_OK;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    hipStream_t s = c->ctx->stream;
+    const size_t need = n * sizeof(double);
+    if (need > c->staging_bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->staging) HIP_TRY(hipFree(c->staging));
+        c->staging = nullptr;
+        c->staging_bytes = 0;
+        HIP_TRY(hipMalloc(&c->staging, need));
+        c->staging_bytes = need;
+    }
+    if (c->rank == root) HIP_TRY(hipMemcpyAsync(c->staging, buf, need, hipMemcpyHostToDevice, s));
+    RCCL_TRY(rccl()->Broadcast(c->staging, c->staging, n, ncclDouble, root, c->comm, s));
+    if (c->rank != root) HIP_TRY(hipMemcpyAsync(buf, c->staging, need, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RL_OK;
 }

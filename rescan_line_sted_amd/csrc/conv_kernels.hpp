@@ -115,6 +115,7 @@ struct ColParams {
     const cx<T>* xs_in = nullptr;   // COL_SPLIT_INV: image frame*in_sb + view*in_sv; COL_SPLIT_INV_SUM: images frame*V + v
     cx<T>* xs_out = nullptr;        // COL_SPLIT_FWD: one per launch row
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
+    int residual = 0;       // the input is the spectrum of `ratio - 1` (H_t of a sub_one plan): compact twiddles may serve it
 };
 
 template <class Cfg, int C, typename T, class Sync>
@@ -213,9 +214,15 @@ enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
 // does not inherit the register footprint of the multi-view loops.
 // (A twiddle copy in LDS like colconv_outer_body's was tried for the fused multi-view modes -- two workgroups per CU, room for it:
 // 512^2 x 4 views 5941 -> 5973 frames/s, noise.  These kernels wait for the vector ALU, not for L1.)
-template <class Cfg, int C, int MODE, typename T, bool REALP = false, class Sync>
+// NYC > 0 (round 4; COL_PER_IMAGE, single-view launches): the image has exactly NYC rows, a multiple of 64 -- which rows of the
+// tile exist is then known at compile time (no row compares, no exec branches around the loads and stores; the rows that do
+// not exist are written to LDS as constants), and the pad columns kx .. pitch - 1 of the last tile are loaded and stored like
+// the others (pitch is a multiple of C: in bounds; nobody reads them as data).
+// CT = 1: compact twiddles in both transforms (the H_t launches of `ratio - 1` plans: fft_core.hpp pass_compute).
+template <class Cfg, int C, int MODE, typename T, bool REALP = false, int NYC = 0, int CT = 0, class Sync>
 RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
+    static_assert(NYC == 0 || (MODE == COL_PER_IMAGE && NYC % 64 == 0 && NYC <= Cfg::L), "compile-time row count");
     constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     constexpr int NT = 64 * C;
@@ -224,34 +231,36 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     using FL = PassInfo<Cfg, false, NP - 1>;
     using IL = PassInfo<Cfg, true, NP - 1>;
     static_assert(!IL::TAIL, "the inverse must end on a lane-local pass");
-    const int w = tid / 64, lane = tid % 64;
+    const int w = rl_uniform(tid / 64), lane = tid % 64;
     const int col0 = bx * C, col = col0 + w;
     const bool colok = col < p.kx;
-    const size_t img = spec_image_elems(p.ny, p.pitch);
+    const int ny = NYC > 0 ? NYC : p.ny;
+    const size_t img = spec_image_elems(ny, p.pitch);
     LdsView<T, 1, LdsGather<L>::value> view_lds{lds + w * LP};
 
-    // tile element e = tid + it*NT  <->  (row = e / C, column c = e % C)
+    // Tile element e = tid + it*NT  <->  (row = e / C = r_lo + 64 it, column c = e % C): one 32-bit byte offset per thread,
+    // the rows of step `it` behind a uniform base -- `scalar base + lane offset` loads and stores, no 64-bit lane arithmetic.
+    const unsigned c_ = (unsigned)tid % C, r_lo = (unsigned)tid / C;
+    const bool cok = NYC > 0 ? true : (int)(col0 + c_) < p.kx;
+    const unsigned boff = (r_lo * (unsigned)p.pitch + (unsigned)col0 + c_) * (unsigned)sizeof(cx<T>);
+    const size_t step = (size_t)64 * p.pitch * sizeof(cx<T>);
     auto load_tile = [&](const cx<T>* __restrict__ in) {
         cx<T> x[NLD];   // all global loads are issued before the first LDS write
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const int row = e / C, c = e % C;
+            const char* sb = reinterpret_cast<const char*>(in) + it * step;
             x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
+            if (cok && (int)(r_lo + 64 * it) < ny) x[it] = rl_ldg(sync, reinterpret_cast<const cx<T>*>(sb + boff));
         }
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
-        }
+        for (int it = 0; it < NLD; ++it) lds[c_ * LP + view_lds.nat(r_lo + 64 * it)] = x[it];
     };
     auto store_tile = [&](cx<T>* __restrict__ out) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const int row = e / C, c = e % C;
-            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(row)], p.qscale);
+            char* sb = reinterpret_cast<char*>(out) + it * step;
+            if (cok && (int)(r_lo + 64 * it) < ny)
+                *reinterpret_cast<cx<T>*>(sb + boff) = rl_spec_round(lds[c_ * LP + view_lds.nat(r_lo + 64 * it)], p.qscale);
         }
     };
     // v, tl *= psf_hat[view] column (register layout of the last forward pass)
@@ -283,7 +292,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     };
     // inverse transform of (v, tl), result in natural order into this wave's LDS column
     auto inverse_to_lds = [&](cx<T>* v, cx<T>& tl, const cx<T>* tw) {
-        run_passes<Cfg, true, 0, true>(v, tl, lane, view_lds, tw, sync);
+        run_passes<Cfg, true, 0, true, CT>(v, tl, lane, view_lds, tw, sync);
         sync.wave();   // last pass' LDS reads are done before the column is overwritten
 #pragma unroll
         for (int nb = 0; nb < IL::NB; ++nb) {
@@ -296,7 +305,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     };
 
     if constexpr (MODE == COL_PER_IMAGE) {
-        const int frame = by / p.V, view = by % p.V;
+        const int frame = NYC > 0 ? by : by / p.V, view = NYC > 0 ? 0 : by % p.V;   // (NYC: single-view launches)
         rl_stamp(sync, 0);
         load_tile(p.in + (size_t)(frame * p.in_sb + view * p.in_sv) * img);
         rl_stamp(sync, 1);
@@ -305,7 +314,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         if (colok) {
             cx<T> v[VMAX];
             cx<T> tl = mk<T>((T)0, (T)0);
-            run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, p.tw, sync);
+            run_passes<Cfg, false, 0, false, CT>(v, tl, lane, view_lds, p.tw, sync);
             rl_stamp(sync, 3);
             multiply(v, tl, view);
             rl_stamp(sync, 4);
@@ -1189,7 +1198,14 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 #ifndef RL_PAIR_NRM_EARLY
 #define RL_PAIR_NRM_EARLY 1
 #endif
-template <class Cfg, int Q, int MODE, typename T, class Sync>
+#ifndef RL_CT_RESIDUAL
+#define RL_CT_RESIDUAL 1      // compact twiddles in the transforms that carry `ratio - 1` (specialised 512-pixel kernels)
+#endif
+// NXC > 0 (round 4): the rows have exactly NXC pixels, a multiple of 64 -- which register slots hold pixels is known at compile
+// time (no selects, no exec branches around the loads and stores).  SUBC: p.sub_one at compile time (-1: run time).
+// An odd frame count: the last pair's second frame is a PHANTOM COPY of its first (it reads the first frame's images and is
+// never stored), so no value of the pointwise stage depends on whether the partner exists.
+template <class Cfg, int Q, int MODE, typename T, int NXC = 0, int SUBC = -1, class Sync>
 RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64 || Q == 1, "one transform per wave, or one (workgroup-synchronous) transform per workgroup");
     static_assert(MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE, "pair modes");
@@ -1201,17 +1217,27 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     static_assert(I0::R == FL::R && I0::NBF == FL::NBF && I0::TAIL == FL::TAIL && I0::NBM == FL::NBM, "spectrum-side layouts must agree");
     static_assert(IL::R == F0::R && IL::NB == F0::NB && !F0::TAIL, "image-side layouts must agree");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
+    static_assert(NXC == 0 || (NXC % 64 == 0 && NXC <= L && TT == 64 && NB == 1 && NBF == 64), "compile-time row length: whole 64-pixel slots");
+    const int nx = NXC > 0 ? NXC : p.nx;
+    const bool sub = SUBC < 0 ? p.sub_one != 0 : SUBC != 0;
     const int q = rl_uniform(tid / TT);
     const int t = tid % TT;
     const int row = bx * Q + q;
     if (row >= p.ny) return;   // a whole wave (wave-private transforms) or the whole workgroup (Q == 1): no barrier is missed
     LdsView<T, 1, LdsGather<L>::value, LdsPadShift<L>::value> view_lds{lds + q * LP};
-    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
+    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * nx;
     // by = pair * V + view (ROW_RATIO of a multi-view plan: measurement images are [frame][view]); V = 1 otherwise
-    const int pr = by / p.V, vw = by % p.V;
+    const int pr = NXC > 0 ? by : by / p.V, vw = NXC > 0 ? 0 : by % p.V;   // (NXC: single-view launches)
+    const int V = NXC > 0 ? 1 : p.V;
     const bool okb = 2 * pr + 1 < p.frames;
-    const size_t ra = ((size_t)(2 * pr * p.V + vw) * p.ny + row) * p.nx, rb = okb ? ra + (size_t)p.V * rimg : ra;   // frame a / b, this row
+    const size_t ra = ((size_t)(2 * pr * V + vw) * p.ny + row) * nx, rb = okb ? ra + (size_t)V * rimg : ra;   // frame a / b, this row
     const int tail_k = (64 + (t & 7)) + bitrev3(t >> 3) * FL::NBF;   // (TAIL passes exist for T == 64 only)
+    // does register slot s hold a pixel?  (NXC: known at compile time, slot by slot)
+    auto in_row = [&](int s) -> bool {
+        const int nb = s / R, r = s % R;
+        if constexpr (NXC > 0) return r * 64 < NXC;
+        else return (t + nb * TT) < NBF && (t + nb * TT) + r * NBF < nx;
+    };
 
     // operands of the pointwise stage: measurement / estimate requested ahead of the inverse transform, the normaliser
     // (an L2 hit: one image shared by all frames) ahead of it too or right behind it (RL_PAIR_NRM_EARLY: registers against waits)
@@ -1225,19 +1251,18 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int i = (t + nb * TT) + r * NBF;
-                const bool inx = (t + nb * TT) < NBF && i < p.nx;
-                pre[nb * R + r] = inx ? mk<T>(s0[i], s1[i]) : mk<T>((T)0, (T)0);
+                pre[nb * R + r] = in_row(nb * R + r) ? mk<T>(s0[i], s1[i]) : mk<T>((T)0, (T)0);
             }
     }
     auto request_norm = [&] {
         if constexpr (MODE == ROW_UPDATE) {
-            const T* __restrict__ n0 = p.norm + (size_t)row * p.nx;
+            const T* __restrict__ n0 = p.norm + (size_t)row * nx;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int i = (t + nb * TT) + r * NBF;
-                    nrm[nb * R + r] = ((t + nb * TT) < NBF && i < p.nx) ? n0[i] : (T)1;
+                    nrm[nb * R + r] = in_row(nb * R + r) ? n0[i] : (T)1;
                 }
         }
     };
@@ -1254,27 +1279,28 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 v[nb * I0::R + r] = j < I0::NBF ? rl_ldg(sync, si + (j + r * I0::NBF)) : mk<T>((T)0, (T)0);
             }
         if constexpr (I0::TAIL) tl = rl_ldg(sync, si + tail_k);
-        run_passes<Cfg, true, 0, true>(v, tl, t, view_lds, p.tw, sync);
+        // (SUBC == 1: the update's inverse transform carries H_t(ratio - 1), the ratio kernel's forward transform ratio - 1)
+        run_passes<Cfg, true, 0, true, (SUBC == 1 && MODE == ROW_UPDATE) ? RL_CT_RESIDUAL : 0>(v, tl, t, view_lds, p.tw, sync);
     }
     if constexpr (RL_PAIR_NRM_EARLY == 0) request_norm();
 #pragma unroll
     for (int s = 0; s < NB * R; ++s) {
         const int nb = s / R, r = s % R;
         const int i = (t + nb * TT) + r * NBF;
-        const bool inx = (t + nb * TT) < NBF && i < p.nx;
+        const bool inx = in_row(s);
         cx<T> z = mk<T>((T)0, (T)0);
         if constexpr (MODE == ROW_FWD) {
-            z = mk<T>(pre[s].re, okb ? pre[s].im : (T)0);
+            z = pre[s];
         } else {
-            const bool sub = p.sub_one != 0;
             if constexpr (MODE == ROW_RATIO) {
-                z.re = inx ? rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub) : (T)0;
-                z.im = inx && okb ? rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub) : (T)0;
+                if (inx) z = mk<T>(rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub), rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub));
             } else {
-                z.re = inx ? pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s], sub) : (T)0;
-                z.im = inx && okb ? pre[s].im * rl_update_factor(sub ? v[s].im : rl_clamp0(v[s].im), nrm[s], sub) : (T)0;
-                if (inx) p.dst[ra + i] = z.re;
-                if (inx && okb) p.dst[rb + i] = z.im;
+                if (inx) {
+                    z = mk<T>(pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s], sub),
+                              pre[s].im * rl_update_factor(sub ? v[s].im : rl_clamp0(v[s].im), nrm[s], sub));
+                    p.dst[ra + i] = z.re;
+                    if (okb) p.dst[rb + i] = z.im;
+                }
             }
         }
         v[s] = z;
@@ -1283,7 +1309,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         if (p.spec_out == nullptr) return;   // last iteration of a run: nobody reads the new estimate's spectrum (uniform)
     }
     if constexpr (MODE != ROW_FWD) fft_sync<Cfg>(sync);   // the inverse's last LDS reads are done
-    run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
+    run_passes<Cfg, false, 0, true, (SUBC == 1 && MODE == ROW_RATIO) ? RL_CT_RESIDUAL : 0>(v, tl, t, view_lds, p.tw, sync);
     cx<T>* __restrict__ so = p.spec_out + (size_t)by * simg + (size_t)row * p.pitch;
 #pragma unroll
     for (int nb = 0; nb < FL::NBM; ++nb)

@@ -121,6 +121,17 @@ template <>
 struct LdsGather<576> {
     static constexpr bool value = RL_LDS_GATHER != 0;
 };
+// L = 576: the first forward exchange (radix 9, 64 butterflies) is conflict free at stride 89 only -- 801 slots = 6.4 KB per f32
+// transform, three 8-wave workgroups per CU, and every f32 RL kernel of this length needs <= 64 registers since round 4, i.e.
+// could keep 8 waves per SIMD.  Capped at 608 slots (stride 66: one ds_read_b64 of the pass takes 4 LDS cycles instead of 2)
+// a transform is 610 slots = 4.9 KB: four workgroups per CU.
+#ifndef RL_LDS_CAP_576
+#define RL_LDS_CAP_576 608
+#endif
+template <>
+struct LdsMaxSlots<576> {
+    static constexpr int value = RL_LDS_CAP_576;
+};
 // the long, workgroup-synchronous lengths (row kernels; f64 column kernels): RL_LDS_GATHER_LONG
 #ifndef RL_LDS_GATHER_LONG
 #define RL_LDS_GATHER_LONG 1   // measured on the row kernels alone: 2048^2 -2 ... -3 %, 4096^2 ROW_RATIO -16 %, ROW_UPDATE -4 %

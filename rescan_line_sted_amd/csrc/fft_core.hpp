@@ -227,6 +227,11 @@ template <int L>
 struct LdsGather {
     static constexpr bool value = false;
 };
+// gathered layout: most LDS slots one exchange may take (0: no cap); fft_configs.hpp sets it for L = 576
+template <int L>
+struct LdsMaxSlots {
+    static constexpr int value = 0;
+};
 
 // View of one transform's LDS storage.  CS = element stride (1 for the row
 // kernels' [fft][idx] layout, C for the column kernels' [idx][column] layout).
@@ -274,13 +279,45 @@ struct PassTw {
         return o;
     }
     static constexpr int OFFSET = offset_();
-    static constexpr int total_() {
+    static constexpr int main_total_() {
         int o = 0;
         for (int d = 0; d < 2; ++d)
             for (int p = 0; p < Cfg::NP; ++p) o += block(d == 1, p);
         return o;
     }
-    static constexpr int TOTAL = total_();
+    // Behind the per-pass blocks, for the cross-lane tail butterflies of the TAIL passes (PassInfo::TAIL): per (direction,
+    // pass P >= 1 with a tail) 64 entries -- the inter-pass twiddle of the ONE tail element lane l holds (input r = l >> 3 of
+    // butterfly 64 + (l & 7); 1 for r = 0, so the multiply needs no lane condition) -- and last one 64-entry block with the
+    // factor of the 8-point DFT's first exchange stage (tail_dft8): lane l, p = l >> 3: exp(-2 pi i (p & 3) / 8) if p >= 4, else 1.
+    static constexpr bool tail_pass(bool inv, int p) {
+        const int r = Cfg::radix(inv ? Cfg::NP - 1 - p : p);
+        return Cfg::T == 64 && r == 8 && Cfg::L / r == 72;
+    }
+    static constexpr int tail_block(bool inv, int p) { return (p > 0 && tail_pass(inv, p)) ? 64 : 0; }
+    static constexpr int tail_offset_() {
+        int o = main_total_();
+        for (int d = 0; d < 2; ++d)
+            for (int p = 0; p < Cfg::NP; ++p) {
+                if (d == (INV ? 1 : 0) && p == P) return o;
+                o += tail_block(d == 1, p);
+            }
+        return o;
+    }
+    static constexpr int TAIL_OFFSET = tail_offset_();
+    static constexpr int w8_offset_() {
+        int o = main_total_();
+        for (int d = 0; d < 2; ++d)
+            for (int p = 0; p < Cfg::NP; ++p) o += tail_block(d == 1, p);
+        return o;
+    }
+    static constexpr int W8_OFFSET = w8_offset_();
+    static constexpr bool any_tail_() {
+        for (int d = 0; d < 2; ++d)
+            for (int p = 0; p < Cfg::NP; ++p)
+                if (tail_pass(d == 1, p)) return true;
+        return false;
+    }
+    static constexpr int TOTAL = W8_OFFSET + (any_tail_() ? 64 : 0);
 };
 
 // Host-side generator of that table (interleaved re, im doubles, 2*TOTAL values).
@@ -296,6 +333,16 @@ inline void fill_pass_twiddles_one(double* out) {
                 dst[2 * ((r - 1) * PI::NBF + j)] = (double)__builtin_cosl(ang);
                 dst[2 * ((r - 1) * PI::NBF + j) + 1] = (double)(INV ? __builtin_sinl(ang) : -__builtin_sinl(ang));
             }
+        if constexpr (PI::TAIL) {   // the tail element of lane l: input r = l >> 3 of butterfly 64 + (l & 7)
+            double* tdst = out + 2 * PassTw<Cfg, INV, P>::TAIL_OFFSET;
+            for (int l = 0; l < 64; ++l) {
+                const int r = l >> 3, j = 64 + (l & 7);
+                const long double num = (long double)r * (long double)(j % PI::NS);
+                const long double ang = 6.283185307179586476925286766559005768L * num / (long double)(PI::NS * PI::R);
+                tdst[2 * l] = (double)__builtin_cosl(ang);
+                tdst[2 * l + 1] = (double)(INV ? __builtin_sinl(ang) : -__builtin_sinl(ang));
+            }
+        }
     }
     if constexpr (P + 1 < Cfg::NP) fill_pass_twiddles_one<Cfg, INV, P + 1>(out);
 }
@@ -303,6 +350,15 @@ template <class Cfg>
 inline void fill_pass_twiddles(double* out) {
     fill_pass_twiddles_one<Cfg, false, 0>(out);
     fill_pass_twiddles_one<Cfg, true, 0>(out);
+    if constexpr (PassTw<Cfg, false, 0>::TOTAL > PassTw<Cfg, false, 0>::W8_OFFSET) {   // forward sign; the inverse conjugates
+        double* dst = out + 2 * PassTw<Cfg, false, 0>::W8_OFFSET;
+        for (int l = 0; l < 64; ++l) {
+            const int p = l >> 3;
+            const long double ang = 6.283185307179586476925286766559005768L * (long double)((p & 4) ? (p & 3) : 0) / 8.0L;
+            dst[2 * l] = (double)__builtin_cosl(ang);
+            dst[2 * l + 1] = (double)(-__builtin_sinl(ang));
+        }
+    }
 }
 
 #ifndef RL_COMPACT_TW
@@ -330,7 +386,10 @@ inline void fill_pass_twiddles(double* out) {
                                      // (3.8e-4 with the deeper products; 3.04e-4 and +2 % with only w^5 and w^7 of a radix-8 butterfly as products),
                                      // past the 3e-4 tests/test_gpu_configs.py asserts.  f64 (below): 9448 -> 9600
 #endif
-template <class Cfg, bool INV, int P, typename T>
+// CT = 1: the compact form whatever the length (round 4: the transforms of an RL iteration that carry `ratio - 1`, a residual
+// of the size of the shot noise -- their rounding error is proportional to what they carry, so the products' extra rounding is
+// of no consequence there, while the transforms that carry the estimate keep their full tables).
+template <class Cfg, bool INV, int P, int CT = 0, typename T>
 RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
     using PI = PassInfo<Cfg, INV, P>;
     constexpr int R = PI::R;
@@ -349,7 +408,7 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
                 // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the
                 // same table: 4/15 of its lines are ever touched), the others are products of two of those (<= 3 roundings deep)
                 constexpr bool COMPACT = RL_COMPACT_TW != 0 && (sizeof(T) == 4 || RL_COMPACT_TW_F64 != 0) && R > 4 &&
-                                         (Cfg::L >= (sizeof(T) == 4 ? RL_COMPACT_TW_MIN_L : RL_COMPACT_TW_MIN_L_F64) || Cfg::L <= RL_COMPACT_TW_SMALL_L);
+                                         (CT != 0 || Cfg::L >= (sizeof(T) == 4 ? RL_COMPACT_TW_MIN_L : RL_COMPACT_TW_MIN_L_F64) || Cfg::L <= RL_COMPACT_TW_SMALL_L);
                 if constexpr (COMPACT) {
                     cx<T> wp[R];
 #pragma unroll
@@ -403,9 +462,12 @@ struct Exchange {
         }
         return extra;
     }
+    // (LdsMaxSlots<L>: a cap on R * S -- the LDS a transform may take -- for lengths whose residency the LDS bounds: the
+    // least-conflict stride under the cap instead of the first conflict-free one)
     static constexpr int pick() {
+        constexpr int cap = LdsMaxSlots<Cfg::L>::value;
         int best = NBF, bc = conflicts(NBF);
-        for (int S = NBF + 1; S <= NBF + 32 && bc > 0; ++S)
+        for (int S = NBF + 1; S <= NBF + 32 && bc > 0 && (cap == 0 || R * S <= cap); ++S)
             if (conflicts(S) < bc) { best = S; bc = conflicts(S); }
         return best;
     }
@@ -546,7 +608,7 @@ RL_HD void fft_sync(Sync& sync) {
 // Lane l = jj + 8*p  (jj = l & 7, p = l >> 3) works on butterfly j = 64 + jj and
 // holds ONE element of it: input r = p of the 8-point DFT, i.e. transform element
 // (64 + jj) + 72*p.  The DFT runs as three radix-2 exchange stages with partners
-// l^32, l^16, l^8.
+// l^32, l^16, l^8 (Sync::bfly).
 //   DIF (natural in  -> bit-reversed out): lane p ends with output k = bitrev3(p)
 //   DIT (bit-reversed in -> natural out):  lane p starts with input k = bitrev3(p)
 // A forward DIF tail followed by an inverse DIT tail chains in registers exactly
@@ -554,37 +616,30 @@ RL_HD void fft_sync(Sync& sync) {
 // ---------------------------------------------------------------------------
 RL_HD int bitrev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
 
-// x *= exp(-+ 2 pi i m / 8), m = 0..3 (runtime, per lane)
-template <bool INV, typename T>
-RL_HD cx<T> mul_w8(cx<T> x, int m) {
-    const T h = (T)0.70710678118654752440084436210485;
-    cx<T> d = mk<T>(h * (x.re + (INV ? -x.im : x.im)), h * (x.im - (INV ? -x.re : x.re)));   // m = 1
-    cx<T> q = rot90<INV>(x);                                                                 // m = 2
-    cx<T> e = mk<T>(h * (q.re + (INV ? -q.im : q.im)), h * (q.im - (INV ? -q.re : q.re)));   // m = 3
-    return m == 0 ? x : (m == 1 ? d : (m == 2 ? q : e));
-}
-
+// Round 4: each exchange stage is Sync::bfly<MASK>(x, lane) -- lanes with the MASK bit clear end with x + partner, lanes
+// with it set with partner - x.  On the device that is two swaps and two additions in which EVERY lane does useful work
+// (dev_sync.hpp: the halves trade real and imaginary parts, so one half adds / subtracts the real parts of both outputs and
+// the other the imaginary parts), where rounds 1-3 fetched the partner's value with a copy, a swap and a select per
+// component, computed sum AND difference and every candidate twiddle product, and selected (46 -> 18 vector instructions
+// per tail).  The factor of the first stage, exp(-+ 2 pi i (p & 3) / 8) on the lanes p >= 4 and 1 elsewhere, is a per-lane
+// table entry `w8` (PassTw::W8_OFFSET; forward sign, the caller conjugates), the second stage's -+i a select.
 template <bool INV, bool DIT, typename T, class Sync>
-RL_HD cx<T> tail_dft8(cx<T> x, int lane, Sync& sync) {
-    const int p = lane >> 3;
-    const bool b2 = (p & 4) != 0, b1 = (p & 2) != 0, b0 = (p & 1) != 0;
-    cx<T> o;
+RL_HD cx<T> tail_dft8(cx<T> x, int lane, cx<T> w8, Sync& sync) {
+    const bool rot = (lane & 24) == 24;   // p & 3 == 3: the lanes whose second-stage factor is -+i
     if constexpr (!DIT) {
-        o = mk<T>(sync.template shfl_xor<32>(x.re), sync.template shfl_xor<32>(x.im));
-        x = b2 ? mul_w8<INV>(o - x, p & 3) : x + o;
-        o = mk<T>(sync.template shfl_xor<16>(x.re), sync.template shfl_xor<16>(x.im));
-        x = b1 ? (b0 ? rot90<INV>(o - x) : o - x) : x + o;
-        o = mk<T>(sync.template shfl_xor<8>(x.re), sync.template shfl_xor<8>(x.im));
-        x = b0 ? o - x : x + o;
+        sync.template bfly<32>(x, lane);
+        x = cmul(x, w8);
+        sync.template bfly<16>(x, lane);
+        const cx<T> q = rot90<INV>(x);
+        x = mk<T>(rot ? q.re : x.re, rot ? q.im : x.im);
+        sync.template bfly<8>(x, lane);
     } else {
-        o = mk<T>(sync.template shfl_xor<8>(x.re), sync.template shfl_xor<8>(x.im));
-        x = b0 ? o - x : x + o;
-        if (b1 && b0) x = rot90<INV>(x);
-        o = mk<T>(sync.template shfl_xor<16>(x.re), sync.template shfl_xor<16>(x.im));
-        x = b1 ? o - x : x + o;
-        if (b2) x = mul_w8<INV>(x, p & 3);
-        o = mk<T>(sync.template shfl_xor<32>(x.re), sync.template shfl_xor<32>(x.im));
-        x = b2 ? o - x : x + o;
+        sync.template bfly<8>(x, lane);
+        const cx<T> q = rot90<INV>(x);
+        x = mk<T>(rot ? q.re : x.re, rot ? q.im : x.im);
+        sync.template bfly<16>(x, lane);
+        x = cmul(x, w8);
+        sync.template bfly<32>(x, lane);
     }
     return x;
 }
@@ -607,9 +662,11 @@ RL_HD int tail_out_index(int lane, int k) {   // Stockham scatter position of ou
 template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, class View, class Sync>
 RL_HD void tail_compute(cx<T>& tl, int lane, View lds, const cx<T>* __restrict__ tw, Sync& sync) {
     using PI = PassInfo<Cfg, INV, P>;
+    cx<T> w8 = tw[PassTw<Cfg, INV, P>::W8_OFFSET + lane];
+    if constexpr (INV) w8.im = -w8.im;
     if constexpr (FROM_REGS) {
         static_assert(PI::NS == 1, "a register-chained tail must be the first pass");
-        tl = tail_dft8<INV, true>(tl, lane, sync);
+        tl = tail_dft8<INV, true>(tl, lane, w8, sync);
     } else {
         if constexpr (View::gathered && P > 0) {   // consumer element j' = 64 + jj, register r' = lane >> 3
             using X = Exchange<Cfg, INV, (P > 0 ? P - 1 : 0)>;
@@ -617,11 +674,8 @@ RL_HD void tail_compute(cx<T>& tl, int lane, View lds, const cx<T>* __restrict__
         } else {
             tl = lds.at(tail_in_index<Cfg, INV, P>(lane));
         }
-        if constexpr (PI::NS > 1) {
-            const int r = lane >> 3, j = 64 + (lane & 7);
-            if (r > 0) tl = cmul(tl, tw[PassTw<Cfg, INV, P>::OFFSET + (r - 1) * PI::NBF + j]);
-        }
-        tl = tail_dft8<INV, false>(tl, lane, sync);
+        if constexpr (PI::NS > 1) tl = cmul(tl, tw[PassTw<Cfg, INV, P>::TAIL_OFFSET + lane]);   // (1 where r = 0)
+        tl = tail_dft8<INV, false>(tl, lane, w8, sync);
     }
 }
 
@@ -631,12 +685,12 @@ RL_HD void tail_compute(cx<T>& tl, int lane, View lds, const cx<T>* __restrict__
 // a TAIL pass additionally `tl` <-> element tail index (64+jj) + 72*bitrev3(p).
 // Every LDS scatter is bracketed by syncs (all threads of the transform --
 // the whole workgroup unless the transform is wave private -- must call this).
-template <class Cfg, bool INV, int P, bool FROM_REGS, typename T, class View, class Sync>
+template <class Cfg, bool INV, int P, bool FROM_REGS, int CT = 0, typename T, class View, class Sync>
 RL_HD void run_passes(cx<T>* v, cx<T>& tl, int t, View lds, const cx<T>* __restrict__ tw, Sync& sync) {
     using PI = PassInfo<Cfg, INV, P>;
     if constexpr (!FROM_REGS) pass_load_lds<Cfg, INV, P>(v, t, lds);
     if constexpr (PI::TAIL) tail_compute<Cfg, INV, P, FROM_REGS>(tl, t, lds, tw, sync);
-    pass_compute<Cfg, INV, P>(v, t, tw);
+    pass_compute<Cfg, INV, P, CT>(v, t, tw);
     if constexpr (P + 1 < Cfg::NP) {
         fft_sync<Cfg>(sync);   // everyone has finished reading the previous LDS contents
         pass_store_lds<Cfg, INV, P>(v, t, lds);
@@ -646,7 +700,7 @@ RL_HD void run_passes(cx<T>* v, cx<T>& tl, int t, View lds, const cx<T>* __restr
             else lds.at(tail_out_index<Cfg, INV, P>(t, k)) = tl;
         }
         fft_sync<Cfg>(sync);
-        run_passes<Cfg, INV, P + 1, false>(v, tl, t, lds, tw, sync);
+        run_passes<Cfg, INV, P + 1, false, CT>(v, tl, t, lds, tw, sync);
     }
 }
 

@@ -64,7 +64,7 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 // NOTE: the transform length is a template parameter of the kernels so that the
 // kernels of different lengths (built in separate translation units) have
 // distinct symbol names.
-template <int L, int C, int MODE, typename T, bool REALP = false>
+template <int L, int C, int MODE, typename T, bool REALP = false, int NYC = 0, int CT = 0>
 __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && MODE == COL_PER_IMAGE && WavePrivate<typename ColCfgFor<L>::type>::value) ? RL_COL_MIN_WAVES : 1)
     k_colconv(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(ColCfgFor<L>::type::T* C, (sizeof(T) == 4 && M
         }
     }
     if constexpr (WavePrivate<KCfg>::value)
-        colconv_wave_body<KCfg, C, MODE, T, REALP>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
+        colconv_wave_body<KCfg, C, MODE, T, REALP, NYC, CT>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
         colconv_body<KCfg, C, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
@@ -196,12 +196,31 @@ static constexpr size_t col_lds_bytes() {
     return (size_t)C * LdsSlots<CCfg>::value * sizeof(cx<T>);
 }
 
+// Kernels specialised for the 512 x 512 frames of the BASELINE headline (L = 576, f32): row / column counts at compile time.
+#ifndef RL_N512
+#define RL_N512 1
+#endif
+template <typename T>
+constexpr bool kColN512 = RL_N512 != 0 && RL_CFG_L == 576 && sizeof(T) == 4;
+
 template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
     const ColParams<T>& p = *static_cast<const ColParams<T>*>(params);
     const dim3 grid(gx, gy), block(CCfg::T * C);
     constexpr size_t lds = col_lds_bytes<C, T>();
     if constexpr (WavePrivate<CCfg>::value) {
+        if constexpr (kColN512<T>) {   // 512 rows exactly, one view: the specialised kernels (conv_kernels.hpp colconv_wave_body NYC)
+            if (p.mode == COL_PER_IMAGE && p.ny == 512 && p.V == 1 && p.pitch % C == 0) {
+                if (p.residual && RL_CT_RESIDUAL) {   // the spectrum is that of `ratio - 1`: compact twiddles
+                    if (p.psf_hat_re) rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T, true, 512, 1>, grid, block, lds, s, p);
+                    else rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T, false, 512, 1>, grid, block, lds, s, p);
+                    return hipGetLastError();
+                }
+                if (p.psf_hat_re) rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T, true, 512>, grid, block, lds, s, p);
+                else rl_launch(k_colconv<RL_CFG_L, C, COL_PER_IMAGE, T, false, 512>, grid, block, lds, s, p);
+                return hipGetLastError();
+            }
+        }
         if (p.psf_hat_re) {   // real PSF spectrum
             if (p.mode == COL_H_MULTI) rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T, true>, grid, block, lds, s, p);
             else if (p.mode == COL_HT_SUM) rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T, true>, grid, block, lds, s, p);
@@ -224,13 +243,13 @@ static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hip
 }
 
 // frame-pair row kernels (rowpair_body)
-template <int L, int Q, int MODE, typename T>
+template <int L, int Q, int MODE, typename T, int NXC = 0, int SUBC = -1>
 __global__ void __launch_bounds__(CfgFor<L>::Cfg::T * Q, (row_min_waves<L, MODE == ROW_FWD ? ROW_RATIO : MODE, true, T>())) k_rowpair(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using KCfg = typename CfgFor<L>::Cfg;
     if constexpr (WavePrivate<KCfg>::value || Q == 1)
-        rowpair_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
+        rowpair_body<KCfg, Q, MODE, T, NXC, SUBC>(p, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<cx<T>*>(smem), s);
 }
 template <int Q, typename T>
 static hipError_t launch_row_pair_t(int mode, const void* params, unsigned gy, hipStream_t s) {
@@ -238,6 +257,14 @@ static hipError_t launch_row_pair_t(int mode, const void* params, unsigned gy, h
         const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
         const dim3 grid((unsigned)((p.ny + Q - 1) / Q), gy), block(Cfg::T * Q);
         const size_t lds = (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>);
+        if constexpr (kColN512<T>) {   // 512-pixel rows, one view, `ratio - 1`: the specialised kernels (rowpair_body NXC / SUBC)
+            if (p.nx == 512 && p.V == 1 && p.sub_one != 0 && mode != ROW_FWD) {
+                if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T, 512, 1>, grid, block, lds, s, p);
+                else if (mode == ROW_UPDATE) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T, 512, 1>, grid, block, lds, s, p);
+                else return hipErrorInvalidValue;
+                return hipGetLastError();
+            }
+        }
         if (mode == ROW_FWD) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_FWD, T>, grid, block, lds, s, p);
         else if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T>, grid, block, lds, s, p);
         else if (mode == ROW_UPDATE) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T>, grid, block, lds, s, p);
@@ -352,6 +379,10 @@ static hipError_t prepare_rows() {
         if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_FWD, T>, bp)) != hipSuccess) return e;
         if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_RATIO, T>, bp)) != hipSuccess) return e;
         if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_UPDATE, T>, bp)) != hipSuccess) return e;
+        if constexpr (kColN512<T>) {
+            if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_RATIO, T, 512, 1>, bp)) != hipSuccess) return e;
+            if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_UPDATE, T, 512, 1>, bp)) != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -360,6 +391,12 @@ static hipError_t prepare() {
     hipError_t e;
     if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
     if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double>, col_lds_bytes<kC64, double>())) != hipSuccess) return e;
+    if constexpr (kColN512<float>) {
+        if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, true, 512>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, false, 512>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, true, 512, 1>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
+        if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, false, 512, 1>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
+    }
     if constexpr (WavePrivate<CCfg>::value) {
         if ((e = allow_lds(k_colconv<RL_CFG_L, kC32, COL_PER_IMAGE, float, true>, col_lds_bytes<kC32, float>())) != hipSuccess) return e;
         if ((e = allow_lds(k_colconv<RL_CFG_L, kC64, COL_PER_IMAGE, double, true>, col_lds_bytes<kC64, double>())) != hipSuccess) return e;

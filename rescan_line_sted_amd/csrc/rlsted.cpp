@@ -110,6 +110,37 @@ struct rl_deconv {
     void* slice_ws = nullptr;                         // per-slice Poisson work lists of run_cycle()
     void *key_seeds = nullptr, *key_ids = nullptr;    // per-frame Philox keys of rl_deconv_simulate_keyed
     size_t slice_ws_bytes = 0, slice_ws_stride = 0;
+    // ---- rl_batch_submit: the tasks of a chunk -- objects, brightness targets, Philox keys -- are staged in one page-locked
+    // block, uploaded on a copy stream of the plan's own and consumed on the context's stream; two blocks, so that chunk i + 1
+    // is staged and uploaded while chunk i iterates.  Block layout (host and device): [B][n_img] float64 objects, [B] float64
+    // targets, [B] uint64 seeds, [B] uint32 image ids; the device block is followed by [B] float64 sums.
+    struct BatchSlot {
+        char* host = nullptr;
+        char* dev = nullptr;
+        hipEvent_t uploaded = nullptr, freed = nullptr;
+        bool used = false;
+    };
+    BatchSlot bslot[2];
+    void* batch_out = nullptr;       // rl_batch_run's result buffer (grow only)
+    size_t batch_out_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    unsigned long batch_chunks = 0;
+    const unsigned long long* run_key_seeds = nullptr;   // keyed Poisson draws of run_slices (device, [B]); nullptr: one seed
+    const unsigned* run_key_ids = nullptr;
+    size_t slot_objects_bytes() const { return (size_t)B * n_img() * sizeof(double); }
+    size_t slot_host_bytes() const { return slot_objects_bytes() + (size_t)B * (8 + 8 + 4); }
+    int ensure_batch_slots() {
+        if (copy_stream) return RL_OK;
+        HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (BatchSlot& sl : bslot) {
+            HIP_TRY(hipHostMalloc((void**)&sl.host, slot_host_bytes(), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**)&sl.dev, slot_host_bytes() + 8 + (size_t)B * sizeof(double)));
+            HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
+            bytes += slot_host_bytes() + 8 + (size_t)B * sizeof(double);
+        }
+        return RL_OK;
+    }
     hipStream_t cur() const { return active ? active : ctx->stream; }
     // column kernel work order: images per block of the tile order (fft_kernels.hip k_colconv):
     // 1 image-major ... >= images per launch: tile-major (RLSTED_COL_ORDER).  Measured at 512^2, 32-frame
@@ -176,6 +207,7 @@ struct rl_deconv {
         p.mode = V == 1 ? COL_PER_IMAGE : (kind == COL_H ? COL_H_MULTI : COL_HT_SUM);
         p.in_sb = 1; p.in_sv = 0;
         p.images = pairs; p.order = col_order;
+        p.residual = (kind != COL_H && sub_one) ? 1 : 0;   // H_t of a `ratio - 1` plan: the spectrum of a residual
         const int C = ty->C[dtype];
         TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
         HIP_TRY(ty->launch_col(dtype, &p, (unsigned)((lx + C - 1) / C), (unsigned)pairs, cur()));
@@ -500,12 +532,14 @@ struct rl_deconv {
     // Host float64 <-> plan dtype.  The conversion (and the brightness scaling) runs on the
     // device: the host array goes over PCIe as it is, in slices of at most kStageElems
     // doubles, through a device staging buffer.
-    static constexpr size_t kStageElems = (size_t)16 << 20;   // 128 MiB of float64
+    static constexpr size_t kStageMax = (size_t)16 << 20;   // at most 128 MiB of float64
+    size_t kStageElems = 0;        // elements of the staging buffer: the plan's largest transfer, capped (a 128-square sweep plan: 4 MB)
     double* stage_dev = nullptr;   // [kStageElems] + per-frame sums / targets
     double* stage_aux = nullptr;   // [B] per-frame targets
     double* stage_sums = nullptr;  // [B * V] per-image sums
     int ensure_stage() {
         if (stage_dev) return RL_OK;
+        kStageElems = std::max(n_img(), std::min(kStageMax, (size_t)B * V * n_img()));
         HIP_TRY(hipMalloc((void**)&stage_dev, kStageElems * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&stage_aux, (size_t)B * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&stage_sums, (size_t)B * V * sizeof(double)));
@@ -517,7 +551,7 @@ struct rl_deconv {
     int upload_images(const double* src, void* dst, size_t count, const double* target, std::vector<double>* sums_out = nullptr) {
         RL_TRY(ensure_stage());
         const size_t n = n_img();
-        if (n > kStageElems) return fail(RL_ERR_UNSUPPORTED, "image larger than the staging buffer");
+        if (n > kStageElems) return fail(RL_ERR_UNSUPPORTED, "image larger than the staging buffer");   // (cannot happen: the buffer holds an image at least)
         const size_t per = kStageElems / n;
         if (sums_out) sums_out->assign(count, 0.0);
         if (target) HIP_TRY(hipMemcpyAsync(stage_aux, target, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -769,8 +803,10 @@ struct rl_deconv {
             RL_TRY(forward_slice(f0, nf));
             void* ws = (char*)slice_ws + (size_t)sl * slice_ws_stride;   // this slice's Poisson work list
             TimedScope t(this, TK_POISSON, false);
+            // (rl_batch_submit: a Philox key per frame, device arrays of B entries)
             hipError_t e = aux_poisson(dtype, off(noiseless, (size_t)f0 * V * n_img()), off(meas, (size_t)f0 * V * n_img()),
-                                       (unsigned)n_img(), (unsigned)(nf * V), (unsigned)(f0 * V), seed, rng_kind, ws, cur());
+                                       (unsigned)n_img(), (unsigned)(nf * V), (unsigned)(f0 * V), seed, rng_kind, ws, cur(),
+                                       run_key_seeds ? run_key_seeds + f0 : nullptr, run_key_ids ? run_key_ids + f0 : nullptr, (unsigned)V);
             if (e != hipSuccess) return fail(RL_ERR_HIP, std::string("Poisson kernels: ") + hipGetErrorString(e));
             return RL_OK;
         };
@@ -895,6 +931,15 @@ int rl_deconv_destroy(rl_deconv* h) {
                     h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
         if (b) hipFree(b);
+    if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
+    for (rl_deconv::BatchSlot& sl : h->bslot) {
+        if (sl.host) hipHostFree(sl.host);
+        if (sl.dev) hipFree(sl.dev);
+        if (sl.uploaded) hipEventDestroy(sl.uploaded);
+        if (sl.freed) hipEventDestroy(sl.freed);
+    }
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    if (h->batch_out) hipFree(h->batch_out);
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1447,35 +1492,132 @@ int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx)
     return RL_OK;
 }
 
-int rl_batch_run(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, double* estimates_out) {
+int rl_batch_submit(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, void* dev_out, int out_dtype) {
     if (!h || (!tasks && n_tasks > 0)) return fail(RL_ERR_INVALID, "NULL argument");
     if (n_tasks < 0 || k_iters < 0) return fail(RL_ERR_INVALID, "negative count");
+    if (rng_kind != RL_RNG_NONE && rng_kind != RL_RNG_PHILOX) return fail(RL_ERR_INVALID, "unknown rng_kind");
+    if (dev_out && out_dtype != RL_F32 && out_dtype != RL_F64) return fail(RL_ERR_INVALID, "out_dtype must be RL_F32 or RL_F64");
+    for (int t = 0; t < n_tasks; ++t) {
+        if (!tasks[t].object) return fail(RL_ERR_INVALID, "task without an object");
+        if ((uint64_t)tasks[t].image_id * (uint64_t)h->V + (uint64_t)h->V > 0xffffffffull) return fail(RL_ERR_INVALID, "image id too large");
+    }
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    RL_TRY(h->ensure_batch_slots());
     const int B = h->B;
     const size_t n = h->n_img();
-    std::vector<double> stage((size_t)B * n), tb(B), est;
-    std::vector<uint64_t> seeds(B);
-    std::vector<uint32_t> ids(B);
-    if (estimates_out) est.resize((size_t)B * n);
+    hipStream_t s = h->ctx->stream;
     for (int t0 = 0; t0 < n_tasks; t0 += B) {
         const int nt = std::min(B, n_tasks - t0);
+        rl_deconv::BatchSlot& sl = h->bslot[h->batch_chunks++ % 2];
+        if (sl.used) HIP_TRY(hipEventSynchronize(sl.freed));   // the chunk before last has consumed this block
+        double* objs = (double*)sl.host;
+        double* tb = (double*)(sl.host + h->slot_objects_bytes());
+        uint64_t* seeds = (uint64_t*)(tb + B);
+        uint32_t* ids = (uint32_t*)(seeds + B);
         bool scaled = true;
+        std::vector<double> level((size_t)B, 0.0);
         for (int f = 0; f < B; ++f) {   // a short last chunk repeats its last task (the plan's batch is fixed)
             const rl_task& t = tasks[t0 + std::min(f, nt - 1)];
-            if (!t.object) return fail(RL_ERR_INVALID, "task without an object");
-            memcpy(&stage[(size_t)f * n], t.object, n * sizeof(double));
+            memcpy(objs + (size_t)f * n, t.object, n * sizeof(double));
             tb[f] = t.total_brightness;
             scaled = scaled && t.total_brightness > 0;
             seeds[f] = t.seed;
             ids[f] = t.image_id;
         }
-        RL_TRY(rl_deconv_set_object(h, stage.data(), scaled ? tb.data() : nullptr));
-        RL_TRY(rl_deconv_simulate_keyed(h, rng_kind, seeds.data(), ids.data()));
-        RL_TRY(rl_deconv_reset_estimate(h));
-        RL_TRY(rl_deconv_iterate(h, k_iters));
-        if (estimates_out) {
-            RL_TRY(rl_deconv_get_estimate(h, est.data()));
-            memcpy(estimates_out + (size_t)t0 * n, est.data(), (size_t)nt * n * sizeof(double));
+        // the frames' levels (what pairs frames of comparable brightness, rl_deconv::choose_loop) are known on the host: the
+        // targets, or -- unscaled objects -- their sums
+        for (int f = 0; f < B; ++f) {
+            if (scaled) {
+                level[f] = tb[f];
+            } else {
+                double t = 0.0;
+                for (size_t i = 0; i < n; ++i) t += objs[(size_t)f * n + i];
+                level[f] = t;
+            }
         }
+        HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, h->slot_host_bytes(), hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipEventRecord(sl.uploaded, h->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
+        const double* d_objs = (const double*)sl.dev;
+        const double* d_tb = (const double*)(sl.dev + h->slot_objects_bytes());
+        const unsigned long long* d_seeds = (const unsigned long long*)(d_tb + B);
+        const unsigned* d_ids = (const unsigned*)(d_seeds + B);
+        double* d_sums = (double*)(sl.dev + (h->slot_host_bytes() + 7) / 8 * 8);
+        // :505-506  obj *= total_brightness / obj.sum(), per frame, on the device
+        HIP_TRY(aux_scale_convert(h->dtype, d_objs, h->obj, n, (size_t)B, scaled ? d_tb : nullptr, d_sums, s, scaled));
+        h->obj_level = level;
+        h->meas_level = level;
+        h->choose_loop(h->meas_level);
+        h->have_obj = true;
+        h->run_key_seeds = d_seeds;
+        h->run_key_ids = d_ids;
+        const int rc = h->run_cycle(k_iters, rng_kind, 0);   // per slice: H(obj), keyed Poisson draws, estimate = 1, k iterations
+        h->run_key_seeds = nullptr;
+        h->run_key_ids = nullptr;
+        HIP_TRY(hipEventRecord(sl.freed, s));
+        sl.used = true;
+        RL_TRY(rc);
+        h->have_meas = true;
+        if (dev_out)
+            HIP_TRY(aux_cast(h->dtype, h->est, out_dtype, (char*)dev_out + (size_t)t0 * n * esize(out_dtype), (size_t)nt * n, s));
+    }
+    return RL_OK;
+}
+
+int rl_batch_run(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters, int rng_kind, double* estimates_out) {
+    if (!h || (!tasks && n_tasks > 0)) return fail(RL_ERR_INVALID, "NULL argument");
+    if (n_tasks < 0 || k_iters < 0) return fail(RL_ERR_INVALID, "negative count");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    const size_t need = (size_t)n_tasks * h->n_img() * esize(h->dtype);
+    if (estimates_out && need > h->batch_out_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+        if (h->batch_out) HIP_TRY(hipFree(h->batch_out));
+        h->batch_out = nullptr;
+        h->batch_out_bytes = 0;
+        HIP_TRY(hipMalloc(&h->batch_out, need));
+        h->batch_out_bytes = need;
+    }
+    RL_TRY(rl_batch_submit(h, tasks, n_tasks, k_iters, rng_kind, estimates_out ? h->batch_out : nullptr, h->dtype));
+    if (estimates_out && n_tasks > 0) return h->download(h->batch_out, estimates_out, (size_t)n_tasks * h->n_img());   // ONE download
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    return RL_OK;
+}
+
+int rl_device_alloc(rl_ctx* ctx, size_t bytes, void** dev_out) {
+    if (!ctx || !dev_out) return fail(RL_ERR_INVALID, "NULL argument");
+    *dev_out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(dev_out, bytes ? bytes : 1));
+    return RL_OK;
+}
+
+int rl_device_free(rl_ctx* ctx, void* dev) {
+    if (!ctx) return fail(RL_ERR_INVALID, "ctx is NULL");
+    if (!dev) return RL_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // nothing queued may still write it
+    HIP_TRY(hipFree(dev));
+    return RL_OK;
+}
+
+int rl_device_download(rl_ctx* ctx, const void* dev, int dtype, size_t n_elements, double* host_out) {
+    if (!ctx || (n_elements && (!dev || !host_out))) return fail(RL_ERR_INVALID, "NULL argument");
+    if (dtype != RL_F32 && dtype != RL_F64) return fail(RL_ERR_INVALID, "dtype must be RL_F32 or RL_F64");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (dtype == RL_F64) {
+        HIP_TRY(hipMemcpyAsync(host_out, dev, n_elements * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return RL_OK;
+    }
+    // f32: widened on the device through the context's float64 scratch, in pieces of at most 128 MiB
+    const size_t piece = std::min(n_elements, (size_t)16 << 20);
+    double* w = nullptr;
+    RL_TRY(ctx->psf_workspace(piece, &w));
+    for (size_t o = 0; o < n_elements; o += piece) {
+        const size_t m = std::min(piece, n_elements - o);
+        HIP_TRY(aux_to_f64(RL_F32, (const char*)dev + o * 4, w, m, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(host_out + o, w, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return RL_OK;
 }

@@ -36,6 +36,13 @@ struct EmuSync {
     }
     template <int MASK>
     float shfl_xor(float v) const { return (float)shfl_xor<MASK>((double)v); }
+    // radix-2 exchange stage (DevSync::bfly): MASK bit clear -> x + partner, set -> partner - x
+    template <int MASK, typename T>
+    void bfly(cx<T>& x, int l) const {
+        const T pr = shfl_xor<MASK>(x.re), pi = shfl_xor<MASK>(x.im);
+        if (l & MASK) x = mk<T>(pr - x.re, pi - x.im);
+        else x = mk<T>(x.re + pr, x.im + pi);
+    }
 };
 
 template <class Body>
@@ -81,6 +88,10 @@ static std::vector<cx<T>> twiddles(bool column = false) {   // rows: CfgFor<L>::
     return twiddles_of<typename CfgFor<L>::Cfg, T>();
 }
 
+// emu_set_special(1): the bodies specialised for a compile-time image size (round 4: NYC / NXC / SUBC / CT template arguments,
+// on the device instantiated for the 512 x 512 frames at L = 576) are run in their L = 256, 192-row / 192-pixel instantiation
+static int g_special = 0;
+
 template <int L, typename T>
 static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitch, int V, int frames,
                  int in_sb, int in_sv, int mode) {
@@ -100,6 +111,12 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
     p.images = gy; p.order = 1;
     run_grid((kx + C - 1) / C, gy, Cfg::T * C, (size_t)C * LdsSlots<Cfg>::value * sizeof(cx<T>),
              [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                 if constexpr (L == 256) {
+                     if (g_special && ny == 192 && V == 1 && mode == COL_PER_IMAGE && pitch % C == 0) {
+                         colconv_wave_body<Cfg, C, COL_PER_IMAGE, T, false, 192, 1>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                         return;
+                     }
+                 }
                  if constexpr (WavePrivate<Cfg>::value)
                      switch (mode) {   // same dispatch as launch_col_t in fft_kernels.hip
                          case COL_H_MULTI: colconv_wave_body<Cfg, C, COL_H_MULTI, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s); break;
@@ -177,6 +194,7 @@ static int row_t(int mode, const T* spec_in, T* spec_out, const T* src, T* dst, 
 extern "C" {
 
 void emu_set_sub_one(int on) { g_sub_one = on; }
+void emu_set_special(int on) { g_special = on; }
 void emu_set_park(int on);
 
 // returns 1 if the column kernel of this length reads psf_hat transposed, 0 if not, <0 unknown L
@@ -325,6 +343,12 @@ static int row_pair_t(int mode, const T* spec_in, T* spec_out, const T* src, T* 
             constexpr int MODE = decltype(mode_tag)::value;
             run_grid((ny + Q - 1) / Q, (frames + 1) / 2, 64 * Q, (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>),
                      [&](int tid, int bx, int by, unsigned char* lds, EmuSync& s) {
+                         if constexpr (L == 256 && MODE != ROW_FWD) {
+                             if (g_special && nx == 192 && p.sub_one) {
+                                 rowpair_body<Cfg, Q, MODE, T, 192, 1>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                                 return;
+                             }
+                         }
                          rowpair_body<Cfg, Q, MODE, T>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
                      });
         };

@@ -426,7 +426,8 @@ def test_split_column_pass(emu, Li, M, ny, kx, real_psf, sum_views):
 def test_frame_pair_row_kernels(emu, L, ny, nx, frames, sfx):
     """rowpair_body: frames 2p / 2p+1 are the real / imaginary part of one complex row transform; the spectrum of a pair
     is [ny][L] complex.  ROW_FWD, ROW_RATIO and ROW_UPDATE against numpy (unnormalised transforms both ways, like
-    the per-frame kernels); an odd frame count leaves the last pair's imaginary part empty."""
+    the per-frame kernels); with an odd frame count the last pair's imaginary part is a PHANTOM copy of its real part's frame
+    (it reads that frame's images and is never stored: no value depends on whether the partner exists)."""
     rt = np.float64 if sfx == 'f64' else np.float32
     ct = np.complex128 if sfx == 'f64' else np.complex64
     tol = 1e-12 if sfx == 'f64' else 3e-5
@@ -434,13 +435,15 @@ def test_frame_pair_row_kernels(emu, L, ny, nx, frames, sfx):
     pairs = (frames + 1) // 2
     f = getattr(emu, 'emu_row_pair_' + sfx)
 
-    def padded(a):               # (frames, ny, nx) real -> (pairs, ny, L) complex
+    def padded(a, phantom=None):   # (frames, ny, nx) real -> (pairs, ny, L) complex; phantom: the odd batch's last imaginary part
         z = np.zeros((pairs, ny, L), dtype=np.complex128)
         for i in range(frames):
             if i % 2 == 0:
                 z[i // 2, :, :nx] += a[i]
             else:
                 z[i // 2, :, :nx] += 1j * a[i]
+        if frames % 2:
+            z[pairs - 1, :, :nx] += 1j * (a[frames - 1] if phantom is None else phantom)
         return z
 
     est = _slack((rng.random((frames, ny, nx)) + 0.5).astype(rt))
@@ -465,7 +468,9 @@ def test_frame_pair_row_kernels(emu, L, ny, nx, frames, sfx):
     assert f(L, ROW_UPDATE, _p(s_in), _p(out), None, _p(est), _p(norm), ny, nx, frames, 0) == 0
     want = est0 * np.maximum(e, 0) / norm.astype(np.float64)
     assert max_rel(est, want) < (1e-12 if sfx == 'f64' else 2e-6)
-    assert max_rel(out, np.fft.fft(padded(want), axis=2)) < tol
+    # (the phantom partner of an odd batch's last frame: that frame's estimate times the factor the imaginary part carries)
+    ph = est0[frames - 1] * np.maximum(z[pairs - 1].imag[:, :nx], 0) / norm.astype(np.float64) if frames % 2 else None
+    assert max_rel(out, np.fft.fft(padded(want, ph), axis=2)) < tol
     # the same two modes on `ratio - 1` (RowParams::sub_one): the stored spectrum is rowFFT(ratio - 1), the update
     # factor max(1 + z / norm, 0)
     emu.emu_set_sub_one.argtypes = [ctypes.c_int]
@@ -479,4 +484,65 @@ def test_frame_pair_row_kernels(emu, L, ny, nx, frames, sfx):
         emu.emu_set_sub_one(0)
     want = est0 * np.maximum(1.0 + e / norm.astype(np.float64), 0)
     assert max_rel(est, want) < (1e-12 if sfx == 'f64' else 2e-6)
-    assert max_rel(out, np.fft.fft(padded(want), axis=2)) < tol
+    ph = est0[frames - 1] * np.maximum(1.0 + z[pairs - 1].imag[:, :nx] / norm.astype(np.float64), 0) if frames % 2 else None
+    assert max_rel(out, np.fft.fft(padded(want, ph), axis=2)) < tol
+
+
+# ------------------------------------------------- bodies specialised for a compile-time image size (round 4)
+def test_compile_time_size_bodies(emu):
+    """colconv_wave_body<..., NYC, CT> and rowpair_body<..., NXC, SUBC> (the device instantiates them for 512 x 512 frames at
+    L = 576) in their L = 256, 192-row / 192-pixel instantiation: identical to the generic bodies' results -- same arithmetic,
+    the row / pixel tests folded at compile time (rows of the tile that do not exist written as constants, pad columns
+    loaded and stored like the others, the phantom partner of an odd batch)."""
+    L, n, frames = 256, 192, 3
+    pairs = (frames + 1) // 2
+    rng = np.random.default_rng(77)
+    emu.emu_set_special.argtypes = [ctypes.c_int]
+    emu.emu_set_sub_one.argtypes = [ctypes.c_int]
+    f = emu.emu_row_pair_f64
+
+    def run_rows(special):
+        emu.emu_set_special(special)
+        emu.emu_set_sub_one(1)
+        try:
+            r = np.random.default_rng(78)
+            zpos = r.random((frames + 1, 7, n)) * 3 + 0.2
+            z = np.zeros((pairs, 7, L), dtype=np.complex128)
+            for i in range(frames + 1):
+                z[i // 2, :, :n] += (1j if i % 2 else 1) * zpos[i]
+            s_pos = _slack(np.fft.fft(z, axis=2) / L)
+            meas = _slack(r.random((frames, 7, n)) * 5 + 1)
+            out = _slack(np.full((pairs, 7, L), np.nan + 1j * np.nan))
+            assert f(L, ROW_RATIO, _p(s_pos), _p(out), _p(meas), None, None, 7, n, frames, 0) == 0
+            ratio_spec = out.copy()
+            est = _slack(r.random((frames, 7, n)) + 0.5)
+            norm = _slack(r.random((7, n)) + 0.5)
+            s_in = _slack(r.standard_normal((pairs, 7, L)) + 1j * r.standard_normal((pairs, 7, L)))
+            assert f(L, ROW_UPDATE, _p(s_in), _p(out), None, _p(est), _p(norm), 7, n, frames, 0) == 0
+            return ratio_spec, est.copy(), out.copy()
+        finally:
+            emu.emu_set_special(0)
+            emu.emu_set_sub_one(0)
+
+    a, b = run_rows(0), run_rows(1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # column pass: 192 rows of 256, one view, 19 spectrum columns (pitch 24: pad columns beside the last tile's valid ones)
+    pl = EmuPlan(emu, [rng.random((1, 5, 3))], n, 36, L, 64)
+    sin = pl.spec(2)
+    sin[:, :, :pl.kx] = rng.random((2, n, pl.kx)) + 1j * rng.random((2, n, pl.kx))
+    outs = []
+    for special in (0, 1):
+        emu.emu_set_special(special)
+        try:
+            sout = pl.spec(2)
+            pl.col(sin, sout, 2, True)
+            outs.append(sout[:, :, :pl.kx].copy())
+        finally:
+            emu.emu_set_special(0)
+    assert np.array_equal(outs[0], outs[1])
+    for b_ in range(2):
+        pad = np.zeros((L, pl.kx), dtype=complex)
+        pad[:n] = sin[b_, :, :pl.kx]
+        ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat_natural[0, :, :pl.kx], axis=0)[:n] * L
+        assert max_rel(outs[1][b_], ref) < 1e-13
