@@ -116,6 +116,13 @@ def _usable_cores():
     return max(1, min(n, 64))
 
 
+def _cgroup_cpu_max():
+    try:
+        return open('/sys/fs/cgroup/cpu.max').read().strip()
+    except OSError:
+        return 'n/a'
+
+
 def _cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -136,6 +143,10 @@ def cpu_baseline(size, budget_s=10.0):
            'sample': '%d frames of the same %dx%d / K=%d workload, numpy float64 oracle, 1 thread, %.1f s'
                      % (frames, size, size, K_ITERS, el)}
     cores = _usable_cores()
+    if cores <= 1:
+        out['all_cores'] = {'skipped': 'usable cores = 1 (sched_getaffinity %d, os.cpu_count %s, cgroup cpu.max %s): nothing to add to the one-core figure'
+                                       % (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else -1, os.cpu_count(), _cgroup_cpu_max()),
+                            'os_cpu_count': os.cpu_count(), 'cpu_model': _cpu_model()}
     if cores > 1:
         import multiprocessing as mp
         t0 = time.perf_counter()
@@ -253,14 +264,19 @@ class StubPlan:
             pass
 
 
-def make_comm(rank, world, local_rank, stub):
+def make_comm(rank, world, local_rank, stub, allow_torch=False):
+    """The product's transport is RCCL through the C ABI (rl_comm_*).  Should it fail to start the run FAILS -- a line measured
+    on another transport is not this product's -- unless --allow-torch-transport asks for torch.distributed explicitly."""
     if stub:
         return TorchComm(local_rank, backend='gloo'), 'torch.distributed gloo (stub)'
+    from rescan_line_sted_amd import sharding
     try:
-        from rescan_line_sted_amd import sharding
         return sharding.RcclComm(rank, world, device=local_rank), 'rl_comm (RCCL through the C ABI)'
-    except Exception as exc:      # the fallback is reported in the output line
-        return TorchComm(local_rank), 'torch.distributed nccl (rl_comm failed: %r)' % (exc,)
+    except Exception as exc:
+        if not allow_torch:
+            raise SystemExit('bench.py: the RCCL communicator of the C ABI did not start (%r); --allow-torch-transport runs on '
+                             'torch.distributed instead' % (exc,))
+        return TorchComm(local_rank), 'torch.distributed nccl (--allow-torch-transport; rl_comm failed: %r)' % (exc,)
 
 
 def accuracy(plan, psf, size, dtype):
@@ -278,7 +294,7 @@ def accuracy(plan, psf, size, dtype):
             'contract': 1e-5 if dtype == 'f32' else 1e-10}
 
 
-def extra_leg(size, n_views, dtype, B, steps, warmup, device, k_iters=K_ITERS):
+def extra_leg(size, n_views, dtype, B, steps, warmup, device, k_iters=K_ITERS, comm=None):
     """`steps` whole cycles (simulate + 20 RL iterations) of `B` frames of another workload shape, timed like the
     headline (synchronise, wall clock, synchronise): BASELINE config 3 (2048 x 2048 line-rescan), config 2's line-rescan
     half (512 x 512, 4 views), the headline in the reference's own arithmetic (float64 plan) and config 5's 4096 x 4096
@@ -290,13 +306,20 @@ def extra_leg(size, n_views, dtype, B, steps, warmup, device, k_iters=K_ITERS):
     for w in range(warmup):
         plan.bench_cycles(k_iters, 1, seed=w)
     plan.ctx.synchronize()
+    if comm is not None:        # N ranks: replicas of the leg, one per GPU, timed like the headline (barriers, maximum over ranks)
+        comm.barrier()
     t0 = time.perf_counter()
     plan.bench_cycles(k_iters, steps, seed=warmup)
     plan.ctx.synchronize()
+    if comm is not None:
+        comm.barrier()
     el = time.perf_counter() - t0
+    world = 1
+    if comm is not None:
+        el, world = comm.allreduce_max(el), comm.world
     est = plan.estimate()
     assert np.isfinite(est).all() and est.min() >= 0
-    value = B * steps / el
+    value = world * B * steps / el
     es = 4 if dtype == 'f32' else 8
     alg = algorithmic_bytes_per_frame(size * size, len(psf), k_iters) * es // 4
     info = plan.info()
@@ -309,18 +332,23 @@ def extra_leg(size, n_views, dtype, B, steps, warmup, device, k_iters=K_ITERS):
         pass
     return {'metric': 'simulated frames/s (%dx%d, %d RL iters)' % (size, size, k_iters), 'value': value, 'unit': 'frames/s',
             'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3, 'dtype': dtype,
+            'n_gpus': world,
             'config': {'workload': name, 'frames_per_gpu_per_step': B, 'n_psf': len(psf), 'rl_iters': k_iters,
                        'fft': '%dx%d' % (info['ly'], info['lx']), 'frame_pairs': plan.strategy()['frame_pairs']},
-            'whole_path': {'algorithmic_bytes_per_frame': alg, 'bytes_per_element': es, 'GBps': alg * value / 1e9,
-                           'frac': alg * value / 1e9 / HBM_PEAK_GBS},
+            'whole_path': {'algorithmic_bytes_per_frame': alg, 'bytes_per_element': es, 'GBps_per_gpu': alg * value / world / 1e9,
+                           'frac': alg * value / world / 1e9 / HBM_PEAK_GBS},
             'rl_iteration_traffic': fabric}
 
 
 # ------------------------------------------------------------------ BASELINE config 4: the sharded figure-2 sweep
+FIG2_DOSES = ('1p0x', '1p5x', '2p0x', '2p5x', '3p0x', '4p0x')
+FIG2_SET_NAMES = tuple(d + k for d in FIG2_DOSES for k in ('_point', '_ld', '_lr'))     # the same order on every rank
+
+
 def fig2_psf_sets(stub):
     """The 18 PSF sets of the sweep: 6 doses x (point-descan, line-descanned, line-rescanned), 1 ... 10 views
     (line_sted_figure_2.py:77-162), made by the product on this rank's device (tune_psf, psf_report, rotations)."""
-    doses = ('1p0x', '1p5x', '2p0x', '2p5x', '3p0x', '4p0x')
+    doses = FIG2_DOSES
     if stub:      # CPU control-flow tests: shapes only
         views = {'_point': [1] * 6, '_ld': [1, 3, 4, 6, 8, 10], '_lr': [2, 3, 4, 6, 8, 10]}
         return {d + k: [np.ones((1, 7, 7))] * v[i] for k, v in views.items() for i, d in enumerate(doses)}
@@ -335,51 +363,91 @@ def fig2_psf_sets(stub):
     return out
 
 
+def fig2_psf_sets_once(comm, rank, stub):
+    """"PSF sets broadcast once" -- the reference builds them once per figure (line_sted_figure_2.py:66-72,164-165).
+    Rank 0 builds the 18 sets; the others receive them through the communicator (two broadcasts: shapes, then values)."""
+    if comm is None or not hasattr(comm, 'bcast'):
+        return fig2_psf_sets(stub), 'built on every rank (no broadcast in this transport)'
+    sets = fig2_psf_sets(stub) if rank == 0 else None
+    meta = np.zeros((len(FIG2_SET_NAMES), 3))
+    if rank == 0:
+        for i, n in enumerate(FIG2_SET_NAMES):
+            meta[i] = (len(sets[n]),) + tuple(np.shape(sets[n][0])[-2:])
+    meta = comm.bcast(meta, 0).astype(np.int64)
+    total = int(sum(v * py * px for v, py, px in meta))
+    flat = np.concatenate([np.asarray(p, dtype=np.float64).ravel() for n in FIG2_SET_NAMES for p in sets[n]]) if rank == 0 else np.zeros(total)
+    flat = comm.bcast(flat, 0)
+    out, o = {}, 0
+    for n, (v, py, px) in zip(FIG2_SET_NAMES, meta):
+        out[n] = [flat[o + k * py * px:o + (k + 1) * py * px].reshape(1, py, px) for k in range(v)]
+        o += v * py * px
+    return out, 'built on rank 0, broadcast once (%d values)' % total
+
+
 def fig2_sweep_leg(comm, rank, world, device, stub):
-    """Config 4 end to end: cost-weighted partition of the 1152 tasks over the ranks (sharding.partition), this rank's
-    shard through sweep.run_tasks (rl_batch_run), one gather on rank 0; run and gather timed separately, maxima over
-    ranks.  No collective in the data path."""
+    """Config 4 end to end: the 1152 tasks dealt to the ranks by plan group (sharding.partition_groups: whole (PSF set, shape)
+    groups, a plan's set-up in the cost), this rank's share enqueued group by group (sweep.run_tasks_device: rl_batch_submit on
+    cached plans, results in one device buffer), ONE device-to-device gather on rank 0 (rl_comm_gather_device: fp32, unpadded) and
+    one download there; run and gather timed separately, maxima over ranks.  No collective in the data path."""
     from rescan_line_sted_amd import sharding, sweep
     objs = np.load(os.path.join(ROOT, 'tests', 'golden', 'objects.npz'))
     objects = {n: objs[n][0].astype(np.float64) for n in ('astronaut', 'cat', 'lines', 'rings')}
     t0 = time.perf_counter()
-    psf_sets = fig2_psf_sets(stub)
+    psf_sets, psf_note = fig2_psf_sets_once(comm, rank, stub)
     t_psf = time.perf_counter() - t0
     tasks = sweep.make_tasks(objects, psf_sets, range(16))
-    costs = sweep.task_costs(tasks, objects, psf_sets, K_ITERS)
-    shards = sharding.partition(costs, world)
+    shards, costs = sweep.shard_sweep(tasks, objects, psf_sets, K_ITERS, world)
+    keys = sweep.task_groups(tasks, objects)
     mine = [tasks[i] for i in shards[rank]]
-    big = (max(o.shape[0] for o in objects.values()), max(o.shape[1] for o in objects.values()))
+    shapes = [tuple(objects[o].shape[-2:]) for o, _, _ in tasks]
+    pix = [sum(shapes[i][0] * shapes[i][1] for i in sh) for sh in shards]
+
+    class HostResults:      # the stub's stand-in for sweep.DeviceResults
+        def __init__(self, ests):
+            self.flat = np.concatenate([e.ravel() for e in ests]) if ests else np.zeros(0)
+
+        def free(self):
+            pass
 
     def run(ts):
         if stub:
             time.sleep(0.001 * len(ts))
-            return [np.ones(objects[o].shape) for o, _, _ in ts]
-        return sweep.run_tasks(ts, objects, psf_sets, K_ITERS, 5e10, 'f32', device)
-    if not stub:
-        run(mine[:4])                       # library / plan warm-up
+            return HostResults([np.ones(objects[o].shape) for o, _, _ in ts])
+        return sweep.run_tasks_device(ts, objects, psf_sets, K_ITERS, 5e10, 'f32', device)
+    t0 = time.perf_counter()
+    run(mine).free()                        # first pass: builds this rank's plans (kept: sweep.plan_for) -- a sweep's set-up
+    t_first = time.perf_counter() - t0
     if comm is not None:
         comm.barrier()
     t0 = time.perf_counter()
-    local = sweep.pad_stack(run(mine), big)
+    res = run(mine)                         # (synchronised inside: every context of the sweep)
     t_run = time.perf_counter() - t0
-    gathered, t_gather = local, 0.0
+    t_gather, transport, gbytes = 0.0, 'none (one rank)', int(sum(pix) * 4)
     if comm is not None:
         t_run = comm.allreduce_max(t_run)
+        t_first = comm.allreduce_max(t_first)
         comm.barrier()
         t0 = time.perf_counter()
-        gathered = comm.gather(local, [len(sh) for sh in shards], 0)
+        if not stub and hasattr(comm, 'gather_device'):
+            flat = comm.gather_device(res, pix, 0)
+            transport = 'rl_comm_gather_device: device buffers, fp32, unpadded, one download on the root'
+        else:
+            flat = comm.gather(res.flat if stub else np.concatenate([e.ravel() for e in res.download()]), pix, 0)
+            transport, gbytes = 'host arrays, float64 (stand-in transport)', int(sum(pix) * 8)
         t_gather = time.perf_counter() - t0
+    else:
+        flat = res.flat if stub else np.concatenate([e.ravel() for e in res.download()])
+    res.free()
     out = {'workload': 'BASELINE config 4: 4 test objects x 6 doses x 3 scan modes x 16 seeds, simulate + %d RL iterations, f32' % K_ITERS,
-           'tasks': len(tasks), 'tasks_per_rank': [len(sh) for sh in shards],
-           'cost_per_rank_rel': [round(sum(costs[i] for i in sh) / (sum(costs) / world), 4) for sh in shards],
-           'seconds_run_max_over_ranks': t_run, 'frames_per_s': len(tasks) / t_run, 'gather_ms': t_gather * 1e3,
-           'gather_bytes': int(len(tasks) * big[0] * big[1] * 8), 'psf_sets_seconds': t_psf,
-           'partition': 'sharding.partition (greedy longest-processing-time, cost = pixels x views x (2 + 2K))'}
+           'tasks': len(tasks), 'seconds_run_max_over_ranks': t_run, 'frames_per_s': len(tasks) / t_run,
+           'seconds_first_pass_with_plan_setup': t_first, 'gather_ms': t_gather * 1e3, 'gather_bytes': gbytes, 'gather_transport': transport,
+           'psf_sets_seconds': t_psf, 'psf_sets': psf_note,
+           'partition': 'sharding.partition_groups: whole (PSF set, shape) plan groups per rank, largest first; cost = pixels x views x '
+                        '(2 + 2K) per task + %d frames of set-up per plan' % sweep.PLAN_SETUP_FRAMES}
+    out.update(sharding.partition_stats(shards, costs, keys))
     if rank == 0:
-        full = sharding.unshard(shards, gathered) if comm is not None else gathered
-        assert full.shape[0] == len(tasks) and np.isfinite(full).all()
-        out['frames_on_root'] = int(full.shape[0])
+        assert flat.shape[0] == sum(pix) and np.isfinite(flat).all()
+        out['frames_on_root'] = len([i for sh in shards for i in sh])
     return out
 
 
@@ -393,6 +461,8 @@ def main():
                     help='fig2sweep: also run BASELINE config 4 (the sharded figure-2 sweep; always run when N > 1)')
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--size', type=int, default=512, choices=(512, 2048))
+    ap.add_argument('--allow-torch-transport', action='store_true',
+                    help='N > 1: fall back to torch.distributed when the RCCL communicator of the C ABI fails to start (default: exit non-zero)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true')
     ap.add_argument('--no-extra-legs', '--no-2048', dest='no_extra', action='store_true',
@@ -427,7 +497,7 @@ def main():
 
     comm, transport = (None, None)
     if world > 1 or 'RANK' in os.environ:
-        comm, transport = make_comm(rank, world, local_rank, stub)
+        comm, transport = make_comm(rank, world, local_rank, stub, args.allow_torch_transport)
 
     if stub:
         plan = StubPlan(psf, B, size, size)
@@ -557,12 +627,22 @@ def main():
     # headline): BASELINE config 3 (2048^2 line-rescan), config 2's line-rescan half, the reference's float64 arithmetic
     if size == 512 and world == 1 and comm is None and not stub and not args.no_extra and args.dtype == 'f32':
         del plan
-        for key, leg, k in (('size_2048', (2048, 4, 'f32', 32, 3, 1), K_ITERS), ('line_rescan_512', (512, 4, 'f32', 128, 5, 1), K_ITERS),
-                            ('f64_512', (512, 1, 'f64', 128, 5, 1), K_ITERS), ('point_2048', (2048, 1, 'f32', 32, 3, 1), K_ITERS),
-                            ('size_4096_k100', (4096, 1, 'f32', 8, 2, 1), 100)):
+        # (every leg >= 0.5 s of timed device work)
+        for key, leg, k in (('size_2048', (2048, 4, 'f32', 32, 5, 1), K_ITERS), ('line_rescan_512', (512, 4, 'f32', 256, 12, 1), K_ITERS),
+                            ('f64_512', (512, 1, 'f64', 256, 20, 1), K_ITERS), ('point_2048', (2048, 1, 'f32', 32, 16, 1), K_ITERS),
+                            ('f64_2048', (2048, 1, 'f64', 16, 10, 1), K_ITERS), ('size_4096_k100', (4096, 1, 'f32', 8, 3, 1), 100)):
             try:
                 out[key] = extra_leg(*leg, local_rank, k)
             except Exception as exc:     # reported, never allowed to void the headline
+                out[key] = {'error': repr(exc)}
+    # N ranks: the 2048 x 2048 shapes as replicas, one per GPU (north star: "throughput on synthetic 512x512 and 2048x2048 images
+    # reported at 1, 2, 4 and 8 GPUs"), timed like the headline
+    if world > 1 and size == 512 and not stub and not args.no_extra and args.dtype == 'f32':
+        del plan
+        for key, leg in (('size_2048', (2048, 4, 'f32', 32, 5, 1)), ('point_2048', (2048, 1, 'f32', 32, 16, 1))):
+            try:
+                out[key] = extra_leg(*leg, local_rank, K_ITERS, comm)
+            except Exception as exc:
                 out[key] = {'error': repr(exc)}
     # BASELINE config 4 through the sharder: whenever there is more than one rank, or on request
     if world > 1 or args.workload == 'fig2sweep':

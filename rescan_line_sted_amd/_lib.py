@@ -145,7 +145,8 @@ def device_count():
 
 
 class Context:
-    """One per GPU (rl_ctx)."""
+    """rl_ctx: a stream and the twiddle tables of one GPU.  One per GPU for ordinary use (stream 0); a sweep deals its
+    plans to a few more of them (`stream` 1, 2, ...) so that the launches of independent plans overlap on the device."""
     _cache = {}
 
     def __init__(self, device=0):
@@ -154,10 +155,10 @@ class Context:
         self.device = device
 
     @classmethod
-    def get(cls, device=0):
-        if device not in cls._cache:
-            cls._cache[device] = Context(device)
-        return cls._cache[device]
+    def get(cls, device=0, stream=0):
+        if (device, stream) not in cls._cache:
+            cls._cache[(device, stream)] = Context(device)
+        return cls._cache[(device, stream)]
 
     def synchronize(self):
         check(lib.rl_ctx_synchronize(self.handle))
@@ -188,13 +189,13 @@ def common_psf_shape(psfs):
 class DeconvPlan:
     """rl_deconv: `batch` frames sharing one PSF set and one image shape."""
 
-    def __init__(self, psfs, batch, ny, nx, dtype='f32', device=0):
+    def __init__(self, psfs, batch, ny, nx, dtype='f32', device=0, stream=0):
         psfs = [as_f64(p) for p in psfs]
         for p in psfs:
             if p.ndim != 3 or p.shape[0] != 1:
                 raise ValueError('PSFs must have shape (1, py, px); got %s' % [q.shape for q in psfs])
         psfs = common_psf_shape(psfs)
-        self.ctx = Context.get(device)
+        self.ctx = Context.get(device, stream)
         self.psf_stack = as_f64(np.concatenate(psfs, axis=0))
         self.V, self.py, self.px = self.psf_stack.shape
         self.B, self.ny, self.nx = int(batch), int(ny), int(nx)
@@ -316,6 +317,23 @@ class DeconvPlan:
         out = np.empty((n, self.ny, self.nx), dtype=np.float64) if fetch else None
         check(lib.rl_batch_run(self.handle, _c.cast(tasks, _vp), n, int(iterations), rng, ptr(out) if fetch else None))
         return out
+
+    def batch_submit(self, objects, total_brightness, seeds, image_ids, iterations, dev_out, out_dtype='f32', rng=RNG_PHILOX):
+        """rl_batch_submit: the same cycle per task, ENQUEUED -- returns once the objects are staged; the estimates go to device
+        memory at `dev_out` (a ctypes.c_void_p / address: n tasks x ny x nx elements of out_dtype, unpadded; None: nowhere).
+        Synchronise the context before reading them."""
+        n = len(objects)
+        tb = np.broadcast_to(np.asarray(0.0 if total_brightness is None else total_brightness, dtype=np.float64), (n,))
+        seeds = np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (n,))
+        ids = np.broadcast_to(np.asarray(image_ids, dtype=np.uint32), (n,))
+        objs = [as_f64(o).reshape(self.ny, self.nx) for o in objects]
+        tasks = (self._Task * n)()
+        for i in range(n):
+            tasks[i].object = objs[i].ctypes.data_as(_dp)
+            tasks[i].total_brightness = float(tb[i])
+            tasks[i].seed = int(seeds[i])
+            tasks[i].image_id = int(ids[i])
+        check(lib.rl_batch_submit(self.handle, _c.cast(tasks, _vp), n, int(iterations), rng, dev_out, DTYPES[out_dtype]))
 
     def bench_cycles(self, k, reps, rng=RNG_PHILOX, seed=0):
         ms = _c.c_double()

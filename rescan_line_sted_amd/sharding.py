@@ -38,6 +38,43 @@ def partition(costs, world_size):
     return [sorted(s) for s in shards]
 
 
+def partition_groups(keys, costs, world_size, setup_frames=0.0, split_at=128, min_piece=64):
+    """Partition tasks over ranks BY GROUP (keys[i]: the group -- device plan -- task i runs in): every rank that touches a
+    group pays the plan's set-up (PSF spectra, normaliser, buffers), so whole groups are dealt, largest first, to the least
+    loaded rank; only groups of `split_at` tasks and more are cut, into pieces of at least `min_piece` tasks.  A piece
+    costs the sum of its tasks' costs plus `setup_frames` times its mean task cost.  Returns task indices per rank (sorted);
+    deterministic, every task assigned exactly once."""
+    costs = np.asarray(costs, dtype=np.float64)
+    groups = {}
+    for i, k in enumerate(keys):
+        groups.setdefault(k, []).append(i)
+    pieces = []
+    for k in sorted(groups, key=repr):
+        idx = groups[k]
+        n_pieces = 1 if len(idx) < split_at else len(idx) // min_piece
+        for part in np.array_split(np.asarray(idx), n_pieces):
+            part = [int(i) for i in part]
+            c = float(costs[part].sum())
+            pieces.append((c + setup_frames * c / len(part), part))
+    order = sorted(range(len(pieces)), key=lambda j: (-pieces[j][0], pieces[j][1][0]))
+    load = [0.0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for j in order:
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        shards[r].extend(pieces[j][1])
+        load[r] += pieces[j][0]
+    return [sorted(s) for s in shards]
+
+
+def partition_stats(shards, costs, keys):
+    """What a bench line reports about a partition: tasks, groups and relative cost per rank."""
+    total = float(sum(costs)) or 1.0
+    world = len(shards)
+    return {'tasks_per_rank': [len(s) for s in shards],
+            'groups_per_rank': [len({keys[i] for i in s}) for s in shards],
+            'cost_per_rank_rel': [round(sum(costs[i] for i in s) / (total / world), 4) for s in shards]}
+
+
 class DeviceArray:
     """Exposes a device buffer owned by a DeconvPlan through
     __cuda_array_interface__ so other libraries can wrap it without a copy."""
@@ -173,6 +210,33 @@ class RcclComm:
             self.handle, self._lib.ptr(local) if local.size else None, sizes, int(root),
             self._lib.ptr(out) if out is not None and out.size else None))
         return out
+
+    def gather_device(self, results, counts, root=0):
+        """The sweep's gather: counts[r] elements of every rank's sweep.DeviceResults buffer, device to device
+        (rl_comm_gather_device: unpadded, the plans' arithmetic type), then ONE download on the root.  Returns the
+        rank-major float64 array there, None elsewhere."""
+        from .sweep import DeviceResults      # (the root's receive buffer is one more of them)
+        total = int(sum(counts))
+        sizes = (ctypes.c_size_t * self.world)(*[int(c) for c in counts])
+        dt = self._lib.DTYPES[results.dtype]
+        if self.rank != root:
+            self._lib.check(self._lib.lib.rl_comm_gather_device(self.handle, results.dev, sizes, dt, int(root), None))
+            return None
+        recv = DeviceResults([(1, total)], results.dtype, self.ctx.device)
+        try:
+            self._lib.check(self._lib.lib.rl_comm_gather_device(self.handle, results.dev, sizes, dt, int(root), recv.dev))
+            self.last_gather_bytes = total * recv.itemsize
+            return recv.download()[0].reshape(-1)
+        finally:
+            recv.free()
+
+    def bcast(self, array, root=0):
+        """A float64 array of the root, on every rank (rl_comm_bcast_host); `array` must have the same shape everywhere."""
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        if a is array:
+            a = a.copy()
+        self._lib.check(self._lib.lib.rl_comm_bcast_host(self.handle, self._lib.ptr(a), a.size, int(root)))
+        return a
 
     def gather_plan(self, plan, counts, which='estimate', root=0, to_host=True):
         """The first counts[r] frames of every rank's plan buffer, straight from device memory (rl_gather).

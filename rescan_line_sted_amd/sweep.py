@@ -2,18 +2,30 @@
 objects x doses x scan modes x seeds"), the workload of the reference's figure-2
 script (line_sted_figure_2.py:29-57: one Deconvolver per PSF set and test image,
 create_data_from_object + N x iterate), batched and -- optionally -- sharded over
-GPUs with `sharding.run_sharded`.
+GPUs.
 
 A task is (object name, PSF-set name, seed).  All tasks that share a PSF set and an image
-shape become the frames of one device plan, whatever their seeds: a frame draws its noise with
-the Philox key (task seed, object id) -- `rl_deconv_simulate_keyed` -- where the object id is the
-position of the object's name in the sorted object names, so a task's result does not depend on
-how the sweep was batched or sharded.
+shape -- a GROUP -- become the frames of one device plan, whatever their seeds: a frame draws its
+noise with the Philox key (task seed, object id) -- `rl_deconv_simulate_keyed` -- where the object
+id is the position of the object's name in the sorted object names, so a task's result does not
+depend on how the sweep was batched or sharded.
+
+How a sweep runs on one rank (round 4; `run_tasks_device`): plans are built once per (PSF set, image
+shape, batch, dtype, device) and kept (`plan_for`); every group is ENQUEUED with `rl_batch_submit` --
+objects staged in page-locked memory, uploaded on a copy stream, simulated and deconvolved on the
+device, the estimates written straight into one device buffer of the rank (`DeviceResults`: fp32 or
+fp64, unpadded, task order) -- on one of a few contexts of the GPU in turn, so that the small launches
+of neighbouring groups overlap; the host synchronises once, at the end.  Across ranks: whole groups
+are dealt to the ranks (`sharding.partition_groups`: a plan's set-up is then paid by one rank), and
+ONE `rl_comm_gather_device` brings the device buffers to the root, which downloads once.
 """
+import ctypes
+import hashlib
+
 import numpy as np
 
 from . import sharding
-from ._lib import DeconvPlan, RNG_PHILOX
+from ._lib import DTYPES, RL_F32, RNG_PHILOX, Context, DeconvPlan, check, lib, ptr
 
 
 def make_tasks(objects, psf_sets, seeds):
@@ -26,59 +38,196 @@ def task_costs(tasks, objects, psf_sets, iterations):
             for o, p, _ in tasks]
 
 
+def task_groups(tasks, objects):
+    """The plan a task runs in: (PSF set, image shape)."""
+    return [(p, tuple(objects[o].shape[-2:])) for o, p, _ in tasks]
+
+
 def object_ids(objects):
     """Stable image ids for the Philox counter: the rank of each object name."""
     return {name: i for i, name in enumerate(sorted(objects))}
 
 
-def run_tasks(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype='f32', device=0,
-              max_frames_per_plan=256):
-    """Run tasks on one GPU.  Returns a list of (ny, nx) estimates in task order."""
-    out = [None] * len(tasks)
+# ------------------------------------------------------------------ plans are built once and kept
+PLAN_CACHE_MAX = 128
+_plans = {}
+
+
+def plan_for(psfs, batch, shape, dtype='f32', device=0, stream=0):
+    """The plan of a (PSF set, image shape, batch): built on first use, kept for the next sweep (the reference builds its
+    Deconvolvers once per figure too, line_sted_figure_2.py:39-45).  `stream`: which of the device's contexts it lives on."""
+    stack = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).reshape((1,) + np.shape(p)[-2:]) for p in psfs]))
+    key = (hashlib.sha1(stack.tobytes()).hexdigest(), stack.shape, int(batch), tuple(shape), dtype, device, stream)
+    plan = _plans.pop(key, None)
+    if plan is None:
+        plan = DeconvPlan([p[None] for p in stack], batch, shape[0], shape[1], dtype=dtype, device=device, stream=stream)
+        while len(_plans) >= PLAN_CACHE_MAX:
+            _plans.pop(next(iter(_plans)))          # the least recently used one
+    _plans[key] = plan
+    return plan
+
+
+def clear_plans():
+    _plans.clear()
+
+
+class DeviceResults:
+    """The estimates of a list of tasks in ONE device buffer (rl_device_alloc): image i at element offsets[i], shape shapes[i],
+    arithmetic type `dtype` -- unpadded, in task order.  What rl_batch_submit writes and rl_comm_gather_device sends."""
+
+    def __init__(self, shapes, dtype='f32', device=0):
+        self.ctx = Context.get(device)
+        self.shapes = [tuple(s) for s in shapes]
+        self.dtype = dtype
+        sizes = [s[0] * s[1] for s in self.shapes]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.n = int(self.offsets[-1])
+        self.itemsize = 4 if DTYPES[dtype] == RL_F32 else 8
+        self.dev = ctypes.c_void_p()
+        check(lib.rl_device_alloc(self.ctx.handle, max(self.n, 1) * self.itemsize, ctypes.byref(self.dev)))
+
+    def address(self, i):
+        return ctypes.c_void_p(self.dev.value + int(self.offsets[i]) * self.itemsize)
+
+    def download(self):
+        """ONE device-to-host transfer; the list of (ny, nx) float64 estimates."""
+        flat = np.empty(self.n, dtype=np.float64)
+        check(lib.rl_device_download(self.ctx.handle, self.dev, DTYPES[self.dtype], self.n, ptr(flat)))
+        return split_flat(flat, self.shapes)
+
+    def free(self):
+        if getattr(self, 'dev', None) is not None and self.dev.value:
+            lib.rl_device_free(self.ctx.handle, self.dev)
+            self.dev = ctypes.c_void_p()
+
+    __del__ = free
+
+
+def split_flat(flat, shapes):
+    out, o = [], 0
+    for s in shapes:
+        out.append(flat[o:o + s[0] * s[1]].reshape(s))
+        o += s[0] * s[1]
+    return out
+
+
+SWEEP_STREAMS = 3      # contexts of one GPU the groups of a sweep are dealt to in turn (their launches overlap)
+
+
+def run_tasks_device(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype='f32', device=0,
+                     max_frames_per_plan=256, streams=SWEEP_STREAMS):
+    """Enqueue the tasks on one GPU (group by group, `rl_batch_submit`), synchronise once; returns their DeviceResults."""
     ids = object_ids(objects)
+    res = DeviceResults([objects[o].shape[-2:] for o, _, _ in tasks], dtype, device)
     groups = {}
-    for idx, (o, p, s) in enumerate(tasks):
-        shape = objects[o].shape[-2:]
-        groups.setdefault((p, shape), []).append(idx)
+    for idx, key in enumerate(task_groups(tasks, objects)):
+        groups.setdefault(key, []).append(idx)
+    used = set()
+    n_sub = 0
     for (p, shape), idxs in groups.items():
         for start in range(0, len(idxs), max_frames_per_plan):
             part = idxs[start:start + max_frames_per_plan]
-            frames = np.stack([np.asarray(objects[tasks[i][0]], dtype=np.float64).reshape(shape) for i in part])
-            plan = DeconvPlan(psf_sets[p], len(part), shape[0], shape[1], dtype=dtype, device=device)
-            est = plan.batch_run(frames, total_brightness, [tasks[i][2] for i in part], [ids[tasks[i][0]] for i in part],
-                                 iterations, rng=RNG_PHILOX)      # rl_batch_run of the C ABI
-            for k, i in enumerate(part):
-                out[i] = est[k]
-            del plan
+            # (the tasks of a piece are consecutive in `res`: a piece is a run of one group's tasks in task order only if
+            # the caller's tasks are grouped; in general every task is submitted to its own address)
+            stream = n_sub % max(1, streams)
+            n_sub += 1
+            plan = plan_for(psf_sets[p], len(part), shape, dtype, device, stream)
+            used.add(stream)
+            frames = [np.ascontiguousarray(np.asarray(objects[tasks[i][0]], dtype=np.float64).reshape(shape)) for i in part]
+            runs = _consecutive_runs(part, res)
+            for a, b in runs:                         # maximal runs of tasks that are neighbours in the result buffer
+                plan.batch_submit(frames[a:b], total_brightness, [tasks[i][2] for i in part[a:b]], [ids[tasks[i][0]] for i in part[a:b]],
+                                  iterations, res.address(part[a]), dtype, rng=RNG_PHILOX)
+    for st in used:
+        Context.get(device, st).synchronize()
+    return res
+
+
+def _consecutive_runs(part, res):
+    """[(a, b)): maximal ranges of `part` whose task indices are consecutive (their images are neighbours in `res`)."""
+    runs, a = [], 0
+    for k in range(1, len(part) + 1):
+        if k == len(part) or part[k] != part[k - 1] + 1:
+            runs.append((a, k))
+            a = k
+    return runs
+
+
+def sort_by_group(tasks, objects):
+    """Task indices ordered so that the tasks of one (PSF set, shape) group are neighbours: one submit per piece."""
+    keys = task_groups(tasks, objects)
+    return sorted(range(len(tasks)), key=lambda i: (keys[i][0], keys[i][1], i))
+
+
+def run_tasks(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype='f32', device=0,
+              max_frames_per_plan=256):
+    """Run tasks on one GPU.  Returns a list of (ny, nx) estimates in task order."""
+    order = sort_by_group(tasks, objects)
+    res = run_tasks_device([tasks[i] for i in order], objects, psf_sets, iterations, total_brightness, dtype, device,
+                           max_frames_per_plan)
+    est = res.download()
+    res.free()
+    out = [None] * len(tasks)
+    for k, i in enumerate(order):
+        out[i] = est[k]
     return out
 
 
 def pad_stack(images, shape):
     """Stack 2-D images of different sizes into one (n, shape[0], shape[1]) array, top-left aligned
-    and zero filled, so that one gather can carry them."""
+    and zero filled."""
     out = np.zeros((len(images),) + tuple(shape), dtype=np.float64)
     for k, im in enumerate(images):
         out[k, :im.shape[0], :im.shape[1]] = im
     return out
 
 
+PLAN_SETUP_FRAMES = 24     # what building a plan costs a rank, in frames of its group's task cost (sharding.partition_groups)
+
+
+def shard_sweep(tasks, objects, psf_sets, iterations, world):
+    """The sweep's partition: whole (PSF set, shape) groups per rank -- a plan is then built, and its set-up paid, on one rank
+    only -- groups of 128 tasks and more in pieces of at least 64.  Returns (shards, costs): task indices per rank, group sorted."""
+    costs = task_costs(tasks, objects, psf_sets, iterations)
+    keys = task_groups(tasks, objects)
+    shards = sharding.partition_groups(keys, costs, world, setup_frames=PLAN_SETUP_FRAMES)
+    order = {i: k for k, i in enumerate(sort_by_group(tasks, objects))}
+    return [sorted(s, key=lambda i: order[i]) for s in shards], costs
+
+
 def figure_2_sweep(objects, psf_sets, seeds, iterations, total_brightness=5e10, dtype='f32',
-                   device=0, comm=None):
+                   device=0, comm=None, info=None):
     """The sweep, sharded over the ranks of `comm` (sharding.RcclComm, or anything with its
     interface) when given.  Returns (tasks, estimates) on rank 0 and (tasks, None) elsewhere;
     estimates is an array (n_tasks, ny, nx) when all objects share a shape, otherwise a list of
-    (ny, nx) arrays in task order (the figure's test objects are 128x128 and 160x160: the
-    single gather then carries frames zero-padded to the largest shape, cropped on rank 0)."""
+    (ny, nx) arrays in task order.  The one gather carries the ranks' estimates unpadded: from device buffer to device
+    buffer in the plans' arithmetic type (`comm.gather_device`), or -- a stand-in communicator without it -- as flat host
+    arrays.  info (dict, optional) receives the partition's statistics."""
     tasks = make_tasks(objects, psf_sets, seeds)
-    costs = task_costs(tasks, objects, psf_sets, iterations)
-    shapes = {tuple(objects[o].shape[-2:]) for o, _, _ in tasks}
-    big = (max(s[0] for s in shapes), max(s[1] for s in shapes))
-
-    def run_local(mine):
-        return pad_stack(run_tasks(mine, objects, psf_sets, iterations, total_brightness, dtype, device), big)
-    padded = sharding.run_sharded(tasks, costs, run_local, comm)
-    if padded is None:
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    shards, costs = shard_sweep(tasks, objects, psf_sets, iterations, world)
+    mine = [tasks[i] for i in shards[rank]]
+    shapes = [tuple(objects[o].shape[-2:]) for o, _, _ in tasks]
+    pix = [sum(shapes[i][0] * shapes[i][1] for i in sh) for sh in shards]
+    if info is not None:
+        info.update(sharding.partition_stats(shards, costs, task_groups(tasks, objects)))
+    if comm is not None and hasattr(comm, 'gather_device'):
+        res = run_tasks_device(mine, objects, psf_sets, iterations, total_brightness, dtype, device)
+        flat = comm.gather_device(res, pix, 0)       # root: host float64, rank-major; others: None
+        res.free()
+    else:
+        local = run_tasks(mine, objects, psf_sets, iterations, total_brightness, dtype, device) if mine else []
+        flat = np.concatenate([np.asarray(e, dtype=np.float64).ravel() for e in local]) if local else np.zeros(0)
+        if comm is not None:
+            flat = comm.gather(flat, pix, 0)
+    if flat is None:
         return tasks, None
-    if len(shapes) == 1:
-        return tasks, padded
-    return tasks, [padded[i][:objects[o].shape[-2], :objects[o].shape[-1]] for i, (o, _, _) in enumerate(tasks)]
+    order = [i for sh in shards for i in sh]
+    parts = split_flat(np.asarray(flat), [shapes[i] for i in order])
+    est = [None] * len(tasks)
+    for k, i in enumerate(order):
+        est[i] = parts[k]
+    if len(set(shapes)) == 1:
+        return tasks, np.stack(est) if est else np.zeros((0,) + (shapes[0] if shapes else (0, 0)))
+    return tasks, est

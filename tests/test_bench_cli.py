@@ -45,7 +45,9 @@ def test_gpus_2_launches_two_ranks_by_itself():
     # N > 1: the line also carries BASELINE config 4 through the sharder (cost-weighted partition, one gather on rank 0)
     sw = d['fig2_sweep']
     assert sw['tasks'] == 1152 and sw['frames_on_root'] == 1152 and sum(sw['tasks_per_rank']) == 1152
-    assert max(sw['cost_per_rank_rel']) < 1.01 and sw['gather_ms'] >= 0
+    # by plan group: the 36 (PSF set, shape) groups are dealt whole, so no plan is set up on two ranks
+    assert sum(sw['groups_per_rank']) == 36 and max(sw['cost_per_rank_rel']) < 1.1 and sw['gather_ms'] >= 0
+    assert 'broadcast' in sw['psf_sets'] or 'every rank' in sw['psf_sets']
 
 
 def test_under_the_drivers_launcher_command():

@@ -66,6 +66,70 @@ def test_batch_run_equals_the_calls_it_is_made_of(lib, small):
         assert np.array_equal(single.estimate()[0], est[i]), i
 
 
+def test_batch_submit_is_batch_run_without_the_host_in_between(lib, small):
+    """rl_batch_submit: the same cycle per task, enqueued -- objects staged in the plan's page-locked blocks (two chunks deep),
+    estimates written to caller-owned device memory in the type asked for; rl_batch_run is a submit plus one download.
+    Several submits in a row, on two plans of two contexts, then ONE synchronisation each."""
+    import ctypes
+    from rescan_line_sted_amd import sweep
+    psf, obj = small
+    objs = [obj * (1 + 0.1 * i) for i in range(7)]
+    seeds, ids = np.arange(21, 28, dtype=np.uint64), np.arange(7, dtype=np.uint32)
+    ref_plan = lib.DeconvPlan(psf, 2, 128, 128, dtype='f32')
+    ref = ref_plan.batch_run(np.stack(objs), 5e10, seeds, ids, 4)         # 4 chunks of 2 (the last one half empty)
+    for out_dtype in ('f32', 'f64'):
+        res = sweep.DeviceResults([(128, 128)] * 7, out_dtype)
+        a = lib.DeconvPlan(psf, 2, 128, 128, dtype='f32')
+        b = lib.DeconvPlan(psf, 3, 128, 128, dtype='f32', stream=1)            # another context: its work overlaps a's
+        a.batch_submit(objs[:4], 5e10, seeds[:4], ids[:4], 4, res.address(0), out_dtype)
+        b.batch_submit(objs[4:], 5e10, seeds[4:], ids[4:], 4, res.address(4), out_dtype)
+        a.ctx.synchronize()
+        b.ctx.synchronize()
+        got = res.download()
+        res.free()
+        for i in range(7):      # frame pairs: a task's partner differs between the chunkings -- f32 rounding level
+            assert max_rel(got[i], ref[i]) < 2e-6, (out_dtype, i)
+        # the same chunking: bit for bit
+        res = sweep.DeviceResults([(128, 128)] * 7, out_dtype)
+        a.batch_submit(objs, 5e10, seeds, ids, 4, res.address(0), out_dtype)
+        a.ctx.synchronize()
+        got = res.download()
+        res.free()
+        for i in range(7):
+            assert np.array_equal(got[i], ref[i]), (out_dtype, i)
+    # unscaled objects (total_brightness <= 0): the levels come from the host sums
+    res = sweep.DeviceResults([(128, 128)] * 2, 'f32')
+    a = lib.DeconvPlan(psf, 2, 128, 128, dtype='f32')
+    a.batch_submit([obj * 1e4, obj * 1.1e4], None, seeds[:2], ids[:2], 3, res.address(0), 'f32')
+    a.ctx.synchronize()
+    got = res.download()
+    a.set_object(np.stack([obj * 1e4, obj * 1.1e4]))
+    a.simulate_keyed(seeds[:2], ids[:2])
+    a.iterate(3)
+    assert np.array_equal(np.stack(got), a.estimate())
+
+
+def test_sweep_results_gather_and_broadcast_world_1(lib, small, tmp_path):
+    """The sweep's transport at world size 1: DeviceResults -> rl_comm_gather_device -> one download; rl_comm_bcast_host."""
+    from rescan_line_sted_amd import sharding, sweep
+    psf, obj = small
+    comm = sharding.RcclComm(0, 1, device=0, path=str(tmp_path / 'id2'))
+    objects = {'rings': obj[None], 'wide': np.tile(obj, (1, 1))[None, :96, :]}
+    psf_sets = {'a': psf, 'b': [psf[0] * 0.5 + 0.5 * psf[0][:, ::-1, :]]}
+    tasks, est = sweep.figure_2_sweep(objects, psf_sets, seeds=(3, 4), iterations=3, comm=comm)
+    tasks1, est1 = sweep.figure_2_sweep(objects, psf_sets, seeds=(3, 4), iterations=3, comm=None)
+    assert tasks == tasks1 and len(est) == len(tasks) == 8
+    for (o, p, s), e, e1 in zip(tasks, est, est1):
+        assert e.shape == objects[o].shape[-2:] and np.array_equal(e, e1)
+    # every task alone gives the same frame up to the pair partner's rounding
+    alone = sweep.run_tasks([tasks[5]], objects, psf_sets, 3)
+    assert max_rel(alone[0], est[5]) < 2e-6
+    x = np.arange(12, dtype=np.float64).reshape(3, 4)
+    assert np.array_equal(comm.bcast(x), x)
+    comm.close()
+    sweep.clear_plans()
+
+
 def test_time_cycle_brackets_every_launch(lib, small):
     psf, obj = small
     plan = lib.DeconvPlan(psf, 8, 128, 128, dtype='f32')

@@ -27,6 +27,33 @@ def test_partition_is_balanced_and_complete():
     assert sharding.partition([1.0], 3) == [[0], [], []]
 
 
+def test_partition_by_plan_group():
+    """sharding.partition_groups: whole (PSF set, shape) groups per rank -- each rank that touches a group pays the plan's
+    set-up -- only groups of 128 tasks and more are cut, into pieces of at least 64; complete, deterministic."""
+    rng = np.random.default_rng(1)
+    views = rng.choice([1, 2, 3, 4, 6, 8, 10], 36)
+    keys, costs = [], []
+    for g in range(36):                                  # figure 2: 36 groups of 32 tasks
+        shape = (128, 128) if g % 2 == 0 else (160, 160)
+        keys += [('set%d' % (g // 2), shape)] * 32
+        costs += [sharding.task_cost(shape[0] * shape[1], int(views[g // 2 * 2]), 20)] * 32
+    for world in (1, 2, 4, 8):
+        shards = sharding.partition_groups(keys, costs, world, setup_frames=24)
+        assert sorted(i for s in shards for i in s) == list(range(len(keys)))
+        assert shards == sharding.partition_groups(keys, costs, world, setup_frames=24)
+        groups_per_rank = [{keys[i] for i in s} for s in shards]
+        assert sum(len(g) for g in groups_per_rank) == 36          # no group is shared between ranks
+        st = sharding.partition_stats(shards, costs, keys)
+        assert st['groups_per_rank'] == [len(g) for g in groups_per_rank] and sum(st['tasks_per_rank']) == len(keys)
+        assert max(st['cost_per_rank_rel']) < 1.35
+    # a group of 300 tasks is cut into 4 pieces of 75 (>= 64), a group of 100 stays whole
+    keys = [('big', (8, 8))] * 300 + [('small', (8, 8))] * 100
+    shards = sharding.partition_groups(keys, [1.0] * 400, 4)
+    sizes = sorted(len(s) for s in shards)
+    assert sizes == [75, 75, 100, 150] and sorted(i for s in shards for i in s) == list(range(400))
+    assert sharding.partition_groups([], [], 3) == [[], [], []]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
