@@ -68,101 +68,98 @@ struct PoissonKeys {
     }
 };
 
-#ifndef RL_POISSON_NT
-#define RL_POISSON_NT 0
-#endif
-// noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510), in two launches so that
-// the rare slow path (log / log-gamma acceptance test, further attempts) does not run
-// with 13 % of the lanes active on every wave:
-//   k_poisson_fast  every pixel: first PTRS attempt; squeeze-accepted pixels are written, the others are
-//                   appended (index only) to the workgroup's segment of a work list: lam >= 10 from the
-//                   front, 0 < lam < 10 (multiplication method) from the back
-//   k_poisson_slow  the listed pixels, densely packed: the front range one PTRS attempt per round, the
-//                   survivors repacked in place between rounds (a wave never waits for its slowest lane's
-//                   fifth attempt); the back range through the multiplication loop
-// Values are a function of (seed, image, pixel) only, so the list order is irrelevant.
-// Each workgroup owns a fixed segment of the work list (capacity = the pixels it
-// visits), fills it through LDS counters and publishes the fill levels in counts[2b], counts[2b+1].
+// noisy = Poisson(noiseless) + 1e-9   (line_sted_tools.py:510).  ONE launch since round 4: a workgroup takes tiles of 2048
+// pixels; every pixel gets the first PTRS attempt (philox_poisson_fast: ~87 % are squeeze-accepted and written at once), the
+// others go -- index and rate -- to a list in LDS: lam >= 10 from the front, 0 < lam < 10 (multiplication method) from the back.
+// The listed pixels are then finished by the same workgroup, densely packed: one PTRS attempt per round (attempt 0 repeats the
+// first candidate and continues into the acceptance test the fast path skipped), the survivors repacked into the other list
+// between rounds -- a wave never waits for its slowest lane's fifth attempt -- and the small rates through the multiplication
+// loop.  Values are a function of (seed, image, pixel) only, so the order is irrelevant: bit for bit what rounds 1-3's two
+// launches (all pixels; then a global work list of the rejected ones, which re-read their rates from global memory: 2.9x the
+// bytes of read + write) produced, and what the numpy twin produces.
+constexpr int kPoissonE = 8, kPoissonTile = 256 * kPoissonE;
 template <typename T>
-__global__ void __launch_bounds__(256) k_poisson_fast(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned n_img,
-                               PoissonKeys keys, int rng_kind, unsigned* __restrict__ list,
-                               unsigned seg_cap, unsigned* __restrict__ counts) {
-    __shared__ unsigned fill, fill_small;
-    if (threadIdx.x == 0) fill = fill_small = 0;
-    __syncthreads();
-    unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
-    const size_t total = (size_t)n_pix * n_img;                  // < 2^32 (aux_poisson)
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-#if RL_POISSON_NT
-        const double lam = (double)__builtin_nontemporal_load(&noiseless[i]);   // read once: keep it out of the caches
-#else
-        const double lam = (double)noiseless[i];
-#endif
-        if (rng_kind != 1) {
-            noisy[i] = (T)(lam + 1e-9);
-            continue;
-        }
-        double k;
-        const unsigned ii = (unsigned)i, img = ii / n_pix, pix = ii - img * n_pix;   // 32-bit division
-        if (philox_poisson_fast(lam, keys.seed(img), keys.image(img), pix, &k)) noisy[i] = (T)(k + 1e-9);
-        else if (lam >= 10.0) seg[atomicAdd(&fill, 1u)] = ii;
-        else seg[seg_cap - 1u - atomicAdd(&fill_small, 1u)] = ii;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        counts[2 * blockIdx.x] = fill;
-        counts[2 * blockIdx.x + 1] = fill_small;
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) k_poisson_slow(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, PoissonKeys keys,
-                               unsigned* __restrict__ list, unsigned seg_cap, const unsigned* __restrict__ counts) {
-    __shared__ unsigned fill;
-    unsigned* seg = list + (size_t)blockIdx.x * seg_cap;
-    unsigned n = counts[2 * blockIdx.x];
-    const unsigned n_small = counts[2 * blockIdx.x + 1];
-    // lam >= 10: attempt `blk` of every pixel still listed (attempt 0 repeats the fast kernel's candidate and
-    // continues into the acceptance test it skipped)
-    for (unsigned blk = 0; n > 0; ++blk) {
-        if (threadIdx.x == 0) fill = 0;
+__global__ void __launch_bounds__(256) k_poisson(const T* __restrict__ noiseless, T* __restrict__ noisy, unsigned n_pix, unsigned total,
+                                                 PoissonKeys keys, int rng_kind) {
+    __shared__ unsigned lst_idx[2][kPoissonTile];
+    __shared__ T lst_lam[2][kPoissonTile];
+    __shared__ unsigned cnt[2], cnt_small;
+    const unsigned tid = threadIdx.x;
+    for (unsigned tile0 = blockIdx.x * (unsigned)kPoissonTile; tile0 < total; tile0 += gridDim.x * (unsigned)kPoissonTile) {
+        if (tid == 0) cnt[0] = cnt_small = 0;
         __syncthreads();
-        const bool last = blk + 1 == kPoissonMaxBlocks;
-        for (unsigned base = 0; base < n; base += blockDim.x) {
-            const unsigned q = base + threadIdx.x;
-            bool again = false;
-            unsigned i = 0;
-            if (q < n) {
-                i = seg[q];
+#pragma unroll
+        for (int e = 0; e < kPoissonE; ++e) {
+            const unsigned i = tile0 + tid + 256u * (unsigned)e;
+            if (i < total) {
+                const T lam_t = noiseless[i];
+                const double lam = (double)lam_t;
+                if (rng_kind != 1) {
+                    noisy[i] = (T)(lam + 1e-9);
+                } else {
+                    const unsigned img = i / n_pix, pix = i - img * n_pix;   // 32-bit division
+                    double k;
+                    if (philox_poisson_fast(lam, keys.seed(img), keys.image(img), pix, &k)) {
+                        noisy[i] = (T)(k + 1e-9);
+                    } else if (lam >= 10.0) {
+                        const unsigned q = atomicAdd(&cnt[0], 1u);
+                        lst_idx[0][q] = i;
+                        lst_lam[0][q] = lam_t;
+                    } else {
+                        const unsigned q = kPoissonTile - 1u - atomicAdd(&cnt_small, 1u);
+                        lst_idx[0][q] = i;
+                        lst_lam[0][q] = lam_t;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (rng_kind != 1) continue;          // (uniform)
+        // lam >= 10: attempt `blk` of every pixel still listed
+        unsigned n = cnt[0];
+        const unsigned n_small = cnt_small;
+        int cur = 0;
+        for (unsigned blk = 0; n > 0; ++blk) {
+            if (tid == 0) cnt[cur ^ 1] = 0;
+            __syncthreads();
+            const bool last = blk + 1 == kPoissonMaxBlocks;
+            for (unsigned q = tid; q < n; q += 256u) {
+                const unsigned i = lst_idx[cur][q];
+                const T lam_t = lst_lam[cur][q];
                 const unsigned img = i / n_pix, pix = i - img * n_pix;
                 const unsigned long long seed = keys.seed(img);
                 double k;
-                const bool done = philox_ptrs_attempt((double)noiseless[i], (unsigned)seed, (unsigned)(seed >> 32), keys.image(img), pix, blk, &k);
-                if (done || last) noisy[i] = (T)((done || k >= 0.0 ? k : 0.0) + 1e-9);
-                else again = true;
+                const bool done = philox_ptrs_attempt((double)lam_t, (unsigned)seed, (unsigned)(seed >> 32), keys.image(img), pix, blk, &k);
+                if (done || last) {
+                    noisy[i] = (T)((done || k >= 0.0 ? k : 0.0) + 1e-9);
+                } else {
+                    const unsigned q2 = atomicAdd(&cnt[cur ^ 1], 1u);   // (at most n <= front region: never reaches the small rates at the back of list 0)
+                    lst_idx[cur ^ 1][q2] = i;
+                    lst_lam[cur ^ 1][q2] = lam_t;
+                }
             }
-            __syncthreads();                                     // this chunk has been read: positions < base + 256 may be rewritten
-            if (again) seg[atomicAdd(&fill, 1u)] = i;
+            __syncthreads();
+            n = cnt[cur ^ 1];
+            cur ^= 1;
         }
-        __syncthreads();
-        n = fill;
-        __syncthreads();
-    }
-    // 0 < lam < 10: multiplication method, one pixel per lane
-    for (unsigned q = threadIdx.x; q < n_small; q += blockDim.x) {
-        const unsigned i = seg[seg_cap - 1u - q];
-        const unsigned img = i / n_pix;
-        noisy[i] = (T)(philox_poisson((double)noiseless[i], keys.seed(img), keys.image(img), i - img * n_pix) + 1e-9);
+        // 0 < lam < 10: multiplication method, one pixel per lane
+        for (unsigned q = tid; q < n_small; q += 256u) {
+            const unsigned at = kPoissonTile - 1u - q, i = lst_idx[0][at];
+            const unsigned img = i / n_pix;
+            noisy[i] = (T)(philox_poisson((double)lst_lam[0][at], keys.seed(img), keys.image(img), i - img * n_pix) + 1e-9);
+        }
+        __syncthreads();                      // the lists are free for the next tile
     }
 }
 
 // ---- host <-> plan staging: float64 host arrays are converted on the device -----------
-// per-frame sums of a float64 stack [frames][n] (one workgroup per frame, wavefront shuffles)
-__global__ void __launch_bounds__(1024) k_frame_sums(const double* __restrict__ x, size_t n, double* __restrict__ sums) {
+// per-frame sums of a stack [frames][n] (one workgroup per frame, wavefront shuffles), accumulated in float64
+template <typename T>
+__global__ void __launch_bounds__(1024) k_frame_sums(const T* __restrict__ x, size_t n, double* __restrict__ sums) {
     __shared__ double part[16];
-    const double* f = x + (size_t)blockIdx.x * n;
+    const T* f = x + (size_t)blockIdx.x * n;
     double v = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) v += f[i];
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) v += (double)f[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -279,30 +276,46 @@ hipError_t aux_box_norm(int dtype, const double* integral_dev, void* out, int V,
 hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n_pix, unsigned n_img, unsigned image0,
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s,
                        const unsigned long long* frame_seeds, const unsigned* frame_ids, unsigned V) {
+    (void)list_ws;   // (rounds 1-3: the global work list between the two launches)
     const PoissonKeys keys{seed, image0, V ? V : 1u, frame_seeds, frame_ids};
     const size_t total = (size_t)n_pix * n_img;
-    if (total >= 0xffffffffull) return hipErrorInvalidValue;      // 32-bit work-list entries
-    const unsigned g = blocks_for(total, 256);
-    // list_ws layout: g segments of seg_cap entries (seg_cap * g <= total + g*256), then 2 g counters
-    const unsigned seg_cap = (unsigned)((total + (size_t)g * 256 - 1) / ((size_t)g * 256)) * 256;
-    unsigned* list = (unsigned*)list_ws;
-    unsigned* counts = list + (size_t)seg_cap * g;               // two per workgroup
-    if (dtype == DT_F32) {
-        k_poisson_fast<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, n_img, keys, rng_kind, list, seg_cap, counts);
-        if (rng_kind == 1) k_poisson_slow<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, keys, list, seg_cap, counts);
-    } else {
-        k_poisson_fast<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, n_img, keys, rng_kind, list, seg_cap, counts);
-        if (rng_kind == 1) k_poisson_slow<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, keys, list, seg_cap, counts);
-    }
+    if (total >= 0xffffffffull - (size_t)kPoissonTile * 4096) return hipErrorInvalidValue;      // 32-bit pixel indices (and their tile stride)
+    if (total == 0) return hipSuccess;
+    const size_t tiles = (total + kPoissonTile - 1) / kPoissonTile;
+    const unsigned g = (unsigned)(tiles > 4096 ? 4096 : tiles);
+    if (dtype == DT_F32) k_poisson<float><<<g, 256, 0, s>>>((const float*)noiseless, (float*)noisy, n_pix, (unsigned)total, keys, rng_kind);
+    else k_poisson<double><<<g, 256, 0, s>>>((const double*)noiseless, (double*)noisy, n_pix, (unsigned)total, keys, rng_kind);
     return hipGetLastError();
 }
 
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
                              double* sums, hipStream_t s, bool want_sums) {
-    if (target || want_sums) k_frame_sums<<<(unsigned)frames, 1024, 0, s>>>(src, n, sums);
+    if (target || want_sums) k_frame_sums<double><<<(unsigned)frames, 1024, 0, s>>>(src, n, sums);
     const unsigned g = blocks_for(n * frames, 256);
     if (dtype == DT_F32) k_scale_convert<float><<<g, 256, 0, s>>>(src, (float*)dst, n, frames, target, sums);
     else k_scale_convert<double><<<g, 256, 0, s>>>(src, (double*)dst, n, frames, target, sums);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_any_negative(const T* __restrict__ x, size_t n, int* __restrict__ flag) {
+    bool neg = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) neg = neg || x[i] < (T)0;
+    if (__any(neg) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+hipError_t aux_any_negative(int dtype, const void* src, size_t n, int* flag, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e != hipSuccess || n == 0) return e;
+    const unsigned g = blocks_for(n, 256);
+    if (dtype == DT_F32) k_any_negative<float><<<g, 256, 0, s>>>((const float*)src, n, flag);
+    else k_any_negative<double><<<g, 256, 0, s>>>((const double*)src, n, flag);
+    return hipGetLastError();
+}
+
+hipError_t aux_image_sums(int dtype, const void* src, size_t n, size_t frames, double* sums, hipStream_t s) {
+    if (frames == 0) return hipSuccess;
+    if (dtype == DT_F32) k_frame_sums<float><<<(unsigned)frames, 1024, 0, s>>>((const float*)src, n, sums);
+    else k_frame_sums<double><<<(unsigned)frames, 1024, 0, s>>>((const double*)src, n, sums);
     return hipGetLastError();
 }
 
@@ -327,9 +340,8 @@ hipError_t aux_cast(int dtype_src, const void* src, int dtype_dst, void* dst, si
 }
 
 size_t aux_poisson_workspace_bytes(size_t total_pixels) {
-    const unsigned g = blocks_for(total_pixels, 256);
-    const size_t seg_cap = (total_pixels + (size_t)g * 256 - 1) / ((size_t)g * 256) * 256;
-    return (seg_cap * g + 2 * (size_t)g) * sizeof(unsigned);
+    (void)total_pixels;
+    return 256;      // (the sampler keeps its work lists in LDS since round 4; the callers' buffers stay for the interface)
 }
 
 }  // namespace rl

@@ -25,6 +25,10 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
 // want_sums: fill `sums` even without a target (the caller reads the frames' levels)
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
                              double* sums, hipStream_t s, bool want_sums = false);
+// *flag = 1 if any of the n values is negative, else 0 (flag: device memory)
+hipError_t aux_any_negative(int dtype, const void* src, size_t n, int* flag, hipStream_t s);
+// sums[f] = sum of image f of a stack [frames][n] in the plan's dtype (float64 accumulation)
+hipError_t aux_image_sums(int dtype, const void* src, size_t n, size_t frames, double* sums, hipStream_t s);
 hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s);
 // dst[i] = (dst type) src[i]: a plan buffer into a result buffer of another arithmetic type (same type: a device copy)
 hipError_t aux_cast(int dtype_src, const void* src, int dtype_dst, void* dst, size_t total, hipStream_t s);

@@ -465,11 +465,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
             const int e = tid + it * NT;
             const int row = M * (e / C) + q, c = e % C;
             x[it] = mk<T>((T)0, (T)0);
-#if defined(RL_DEBUG_NOLOAD)
-            x[it] = mk<T>((T)row, (T)c);
-#else
             if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
-#endif
         }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -482,11 +478,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
         for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * NT;
             const int row = M * (e / C) + q, c = e % C;
-#if defined(RL_DEBUG_NOSTORE)
-            if (row < p.ny && col0 + c < p.kx && lds[c * LP + view_lds.nat(e / C)].re == (T)-1.2345e30) out[spec_off(row, col0 + c, p.pitch)] = lds[c * LP];
-#else
             if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(e / C)], p.qscale);
-#endif
         }
     };
     // element index (within the core transform) a lane holds in register slot s; s == NV: the tail element

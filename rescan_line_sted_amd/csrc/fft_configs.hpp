@@ -274,7 +274,7 @@ struct OuterCol<4608> {
     static constexpr int M = 8, C = 8, CW = 8, MIN_WAVES = 2;   // one 8-wave workgroup per CU, 256 registers per lane
     static constexpr bool SPLIT = true;    // 4096^2, 4 views: 33.5 -> 45 frames/s
 #ifndef RL_PARK_4608
-#define RL_PARK_4608 10
+#define RL_PARK_4608 14
 #endif
 #ifndef RL_TWLDS_4608
 #define RL_TWLDS_4608 2
@@ -284,7 +284,7 @@ struct OuterCol<4608> {
 #define RL_TWLDS_SPLIT_4608 2
 #endif
     static constexpr int TWLDS_SPLIT = RL_TWLDS_SPLIT_4608;
-    static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 41 KB of parking space beside 51.3 KB (10 values are enough for no scratch)
+    static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 57 KB of parking space beside 39 KB of transforms (round 4: 10 values left 40-52 bytes of scratch per lane at HEAD, 14 leave 8-20)
 };
 
 // geometry sanity: a workgroup is T*C (column kernel) / T*Q (row kernels) threads

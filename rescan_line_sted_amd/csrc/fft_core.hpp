@@ -398,11 +398,7 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
         const int j = t + nb * Cfg::T;
         if (j < PI::NBF) {
             if constexpr (PI::NS > 1) {
-#if defined(RL_DEBUG_TW0)   // timing study only (wrong results): every lane reads the same twiddles -- what the table's L2 traffic costs
-                const cx<T>* __restrict__ w = tw + PassTw<Cfg, INV, P>::OFFSET + (Cfg::L >= 1152 ? 0 : j);
-#else
                 const cx<T>* __restrict__ w = tw + PassTw<Cfg, INV, P>::OFFSET + j;
-#endif
                 // COMPACT (the long f32 transforms, whose tables -- 69 KB at L = 2304 -- do not stay in L1: 53 of the row kernels'
                 // 79 vector loads are twiddles, 2x the data's bytes out of L2; all lanes reading ONE entry instead measured 2048^2
                 // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the

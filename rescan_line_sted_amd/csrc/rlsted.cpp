@@ -86,6 +86,13 @@ struct rl_deconv {
     // path (RLSTED_EXACT_NORM=0: off), and -- non-negative PSFs -- the second half of every iteration on `ratio - 1`
     // (RLSTED_SUB_ONE=0: off).  Both shrink f32 rounding error, neither changes the arithmetic in exact terms.
     bool exact_norm = false, sub_one = false;
+    // `ratio - 1` clamps the SUM of the views' back-projections where the reference clamps each view's (ref:587).  The two agree
+    // whenever no view's term is negative -- always for one view, and for several as long as the measurement has no negative
+    // pixel (PSFs >= 0 is a condition of sub_one).  A multi-view measurement WITH negative pixels (background-subtracted data
+    // through rl_deconv_set_measurement) therefore runs the plain arithmetic with the per-view clamp; so does RLSTED_FUSE_VIEWS=0,
+    // the switch that asks for the reference's per-view clamp.
+    bool meas_negative = false;
+    bool sub() const { return sub_one && !(V > 1 && meas_negative); }
     void* obj = nullptr;       // [B][ny][nx]
     void* noiseless = nullptr; // [B*V][ny][nx]
     void* meas = nullptr;      // [B*V][ny][nx]
@@ -181,6 +188,35 @@ struct rl_deconv {
             spec_valid = false;   // spec_a holds the other layout's spectra
         }
     }
+    // The measurement buffer was handed out (rl_deconv_device_ptr which = 1) and may have been written on the device: the per-frame
+    // sums are recomputed there before the next run decides between the pair loop and the per-frame loop.
+    bool meas_external = false;
+    int refresh_meas_levels() {
+        if (!meas_external) return RL_OK;
+        RL_TRY(ensure_stage());
+        std::vector<double> sums((size_t)B * V);
+        HIP_TRY(aux_image_sums(dtype, meas, n_img(), (size_t)B * V, stage_sums, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(sums.data(), stage_sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        meas_level.assign((size_t)B, 0.0);
+        for (size_t i = 0; i < sums.size(); ++i) meas_level[i / V] += sums[i];
+        choose_loop(meas_level);
+        RL_TRY(scan_meas_negative());
+        meas_external = false;
+        return RL_OK;
+    }
+    // does the measurement on the device hold a negative pixel?  (multi-view plans only: see sub())
+    int scan_meas_negative() {
+        meas_negative = false;
+        if (V < 2 || !sub_one) return RL_OK;
+        RL_TRY(ensure_stage());
+        int flag = 0;
+        HIP_TRY(aux_any_negative(dtype, meas, (size_t)B * V * n_img(), (int*)stage_aux, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&flag, stage_aux, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        meas_negative = flag != 0;
+        return RL_OK;
+    }
     bool keep_last_spectrum = false;   // RLSTED_KEEP_LAST_SPECTRUM=1: every iteration ends with rowFFT(estimate)
     bool drop_last_spectrum = false;   // set by run_slices for the last iteration of a long run: ROW_UPDATE skips rowFFT(estimate)
     void *psf_hat_pair = nullptr, *psf_hat_pair_re = nullptr;   // psf_hat at full width: [lx][ly] (transposed layout)
@@ -207,7 +243,7 @@ struct rl_deconv {
         p.mode = V == 1 ? COL_PER_IMAGE : (kind == COL_H ? COL_H_MULTI : COL_HT_SUM);
         p.in_sb = 1; p.in_sv = 0;
         p.images = pairs; p.order = col_order;
-        p.residual = (kind != COL_H && sub_one) ? 1 : 0;   // H_t of a `ratio - 1` plan: the spectrum of a residual
+        p.residual = (kind != COL_H && sub()) ? 1 : 0;   // H_t of a `ratio - 1` plan: the spectrum of a residual
         const int C = ty->C[dtype];
         TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
         HIP_TRY(ty->launch_col(dtype, &p, (unsigned)((lx + C - 1) / C), (unsigned)pairs, cur()));
@@ -230,7 +266,7 @@ struct rl_deconv {
     int row_pair_t(int mode, int frames, const void* spec_in, void* spec_out, const void* src, void* dst, const void* nrm, int in_mod, int views) {
         RowParams<T> p;
         p.in_mod = in_mod;
-        p.sub_one = sub_one ? 1 : 0;
+        p.sub_one = sub() ? 1 : 0;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -482,7 +518,7 @@ struct rl_deconv {
               const void* scale, int views, int in_mod = 0) {
         RowParams<T> p;
         p.in_mod = in_mod;
-        p.sub_one = sub_one ? 1 : 0;
+        p.sub_one = sub() ? 1 : 0;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -980,12 +1016,6 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         {&h->noiseless, B * V * h->n_img() * es},     {&h->meas, B * V * h->n_img() * es},
         {&h->est, B * h->n_img() * es},               {&h->norm, h->n_img() * es},
         {&h->scratch, std::max(B * V * h->n_img() * es, aux_poisson_workspace_bytes(B * V * h->n_img()))}};   // also the Poisson work list
-    if (h->col_split()) {
-        const size_t n = B * V * h->n_spec_x() * 2 * es;
-        HIP_TRY(hipMalloc(&h->spec_x, n));
-        HIP_TRY(hipMemsetAsync(h->spec_x, 0, n, ctx->stream));
-        h->bytes += n;
-    }
     for (const Req& r : reqs) {
         // RL_STREAM_SLACK: the streaming row kernels load whole 64-lane segments without clamping;
         // lanes past the end of the last row of a buffer read (and discard) these bytes
@@ -1039,6 +1069,13 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         } else {
             (void)hipFree(re);
         }
+    }
+    // The split column pass parks B * V column spectra (24 MB per 2048^2 image).  The set-up below runs it on ONE frame (H(1)); the
+    // full allocation follows the strategy selection further down: a plan that ends on the separable stencils never touches it.
+    if (h->col_split()) {
+        const size_t n = V * h->n_spec_x() * 2 * es;
+        HIP_TRY(hipMalloc(&h->spec_x, n));
+        HIP_TRY(hipMemsetAsync(h->spec_x, 0, n, ctx->stream));
     }
     // H_t(ones), line_sted_tools.py:589-592: sum_v clamp(conv(ones, psf_v))
     HIP_TRY(aux_fill(h->dtype, h->est, h->n_img(), 1.0, ctx->stream));
@@ -1157,6 +1194,17 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
     }
+    if (h->col_split()) {   // (the one-frame parking space of the set-up -> the plan's, unless the stencils took over)
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(h->spec_x));
+        h->spec_x = nullptr;
+        if (!h->sep) {
+            const size_t n = B * V * h->n_spec_x() * 2 * es;
+            HIP_TRY(hipMalloc(&h->spec_x, n));
+            HIP_TRY(hipMemsetAsync(h->spec_x, 0, n, ctx->stream));
+            h->bytes += n;
+        }
+    }
     // ---- frame pairs for the Richardson-Lucy loop (single view, even batch, wave-private lengths) ----
     // Default: f32 plans (the throughput mode).  f64 plans keep every frame's arithmetic independent of its neighbour in the
     // batch (a pair's two frames share rounding errors: 1e-16-level differences with the partner frame).
@@ -1243,7 +1291,9 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
         bool nonneg = true;
         for (size_t i = 0; i < (size_t)n_psf * py * px && nonneg; ++i) nonneg = psfs[i] >= 0.0;
         const bool want = getenv("RLSTED_SUB_ONE") ? atoi(getenv("RLSTED_SUB_ONE")) != 0 : (dtype == RL_F32 && RL_SPEC_QUANT == 0);
-        h->sub_one = want && nonneg;
+        // (RLSTED_FUSE_VIEWS=0 selects the reference's per-view clamp in H_t: `ratio - 1` clamps the view sum, so it is off then)
+        const bool per_view_clamp = n_psf > 1 && getenv("RLSTED_FUSE_VIEWS") && atoi(getenv("RLSTED_FUSE_VIEWS")) == 0;
+        h->sub_one = want && nonneg && !per_view_clamp;
     }
     int r = deconv_build(h, psfs);
     if (r != RL_OK) {
@@ -1294,6 +1344,7 @@ int rl_deconv_simulate(rl_deconv* h, int rng_kind, uint64_t seed) {
     h->meas_level = h->obj_level;   // the measurement's level follows the object's
     h->choose_loop(h->meas_level);
     h->have_meas = true;
+    h->meas_external = false;
     h->est_ready = false;
     return RL_OK;
 }
@@ -1317,6 +1368,8 @@ int rl_deconv_simulate_keyed(rl_deconv* h, int rng_kind, const uint64_t* seeds, 
     HIP_TRY(hipStreamSynchronize(h->ctx->stream));   // the host arrays may go away
     h->meas_level = h->obj_level;
     h->choose_loop(h->meas_level);
+    h->meas_external = false;
+    h->meas_negative = false;   // (Poisson draws + 1e-9)
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;
@@ -1331,7 +1384,10 @@ int rl_deconv_set_measurement(rl_deconv* h, const double* noisy) {
         h->meas_level.assign((size_t)h->B, 0.0);
         for (size_t i = 0; i < sums.size(); ++i) h->meas_level[i / h->V] += sums[i];
         h->choose_loop(h->meas_level);
+        RL_TRY(h->scan_meas_negative());
     }
+    h->meas_external = false;
+    h->meas_negative = false;   // (Poisson draws + 1e-9)
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;
@@ -1357,6 +1413,7 @@ int rl_deconv_iterate(rl_deconv* h, int k) {
     if (k < 0) return fail(RL_ERR_INVALID, "k < 0");
     if (!h->have_meas) return fail(RL_ERR_STATE, "no measurement: call rl_deconv_simulate or rl_deconv_set_measurement");
     HIP_TRY(hipSetDevice(h->ctx->device));
+    RL_TRY(h->refresh_meas_levels());
     HIP_TRY(hipEventRecord(h->ev0, h->ctx->stream));
     bool restart = !h->est_ready;
     if (!restart && !h->spec_valid && h->pair) {
@@ -1628,7 +1685,14 @@ int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements
     size_t n = 0;
     switch (which) {
         case 0: p = h->est; n = (size_t)h->B * h->n_img(); break;
-        case 1: p = h->meas; n = (size_t)h->B * h->V * h->n_img(); break;
+        case 1:
+            p = h->meas;
+            n = (size_t)h->B * h->V * h->n_img();
+            // The caller may write a measurement straight into this buffer: what the host knows about the frames' levels (the
+            // pairing guard, choose_loop) is then void -- the next run recomputes them from the buffer (refresh_meas_levels).
+            h->meas_level.clear();
+            h->meas_external = true;
+            break;
         case 2: p = h->noiseless; n = (size_t)h->B * h->V * h->n_img(); break;
         case 3: p = h->obj; n = (size_t)h->B * h->n_img(); break;
         default: return fail(RL_ERR_INVALID, "which must be 0..3");

@@ -14,6 +14,9 @@
 // results staged in LDS; the Richardson-Lucy pointwise steps are its epilogues (ref:520-531).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
+
 #include <cstdlib>
 
 #include "sep_kernels.hpp"
@@ -260,15 +263,22 @@ hipError_t cols_t(int mode, const void* tmp, const void* u, const void* aux, con
     const dim3 grid((unsigned)((nx + kColW - 1) / kColW), (unsigned)((ny + kColH - 1) / kColH), (unsigned)frames_or_images);
     const size_t lds = (size_t)(kColH + py - 1) * kColW * sizeof(T);
     if (lds > kSepMaxLds) return hipErrorInvalidValue;   // (the plan does not choose the stencils for such a PSF: sep_cols_fits)
-    if (lds > 65536) {   // above the default dynamic-LDS limit: raise it, once per kernel
-        static const hipError_t raised = [] {
-            hipError_t e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
+    if (lds > 65536) {   // above the default dynamic-LDS limit: raise it, once per kernel AND DEVICE (the attribute belongs to the
+                         // device's code object: a process-wide flag would leave a second GPU without it; a failure is not cached)
+        static std::mutex mu;
+        static std::set<int> raised;
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!raised.count(dev)) {
+            e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_RATIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_SUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sep_cols<T, SEP_UPDATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSepMaxLds);
-            return e;
-        }();
-        if (raised != hipSuccess) return raised;
+            if (e != hipSuccess) return e;
+            raised.insert(dev);
+        }
     }
     switch (mode) {
         case SEP_STORE: k_sep_cols<T, SEP_STORE><<<grid, 256, lds, s>>>((const T*)tmp, (const T*)u, (const T*)aux, (const T*)norm, (T*)dst, ny, nx, py, V); break;

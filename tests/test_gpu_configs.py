@@ -223,6 +223,67 @@ def test_frame_pairs_need_partners_of_comparable_brightness(lib, golden, astrona
     assert ok.strategy()['frame_pairs']
 
 
+def test_measurement_written_through_the_device_pointer_is_not_paired_blindly(lib, golden, astronaut512):
+    """rl_deconv_device_ptr(which = 1) hands out the measurement buffer (the zero-copy drop-in path); what the host
+    knew about the frames' levels is void from then on, so the next run recomputes the per-frame sums on the device before it
+    chooses between the pair loop and the per-frame loop."""
+    torch = pytest.importorskip('torch')
+    psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
+    plan = lib.DeconvPlan(psf, 4, 512, 512, dtype='f32')
+    plan.set_object(np.stack([astronaut512] * 4), 8e11)
+    plan.simulate(seed=5)
+    assert plan.strategy()['frame_pairs']
+    m = torch.as_tensor(plan.device_array('measurement'), device='cuda')
+    m[1] *= 1e-4                                          # frame 1 now 1e4 times dimmer than its partner
+    torch.cuda.synchronize()
+    plan.reset_estimate()
+    plan.iterate(2)
+    assert not plan.strategy()['frame_pairs']             # the per-frame loop ran
+    m[1] *= 1e4
+    torch.cuda.synchronize()
+    plan.device_array('measurement')                      # (handing it out again: the levels are looked at again)
+    plan.reset_estimate()
+    plan.iterate(2)
+    assert plan.strategy()['frame_pairs']
+
+
+def test_multi_view_measurement_with_negative_pixels_keeps_the_per_view_clamp(lib, golden, monkeypatch):
+    """`ratio - 1` clamps the SUM of the views' back-projections, the reference each view's (ref:587); they agree
+    unless a view's term is negative, which takes a negative measurement pixel.  A multi-view f32 plan whose uploaded
+    measurement has negative pixels (background-subtracted data) therefore runs the plain arithmetic: bit for bit what
+    RLSTED_SUB_ONE=0 gives, and the float64 plan's result within the f32 margin; so does RLSTED_FUSE_VIEWS=0."""
+    psfs = [p[None] for p in golden('g8_fig2_psfs')['1p5x_lr/line_sted_psfs'][:, 0]]
+    obj = golden('objects')['rings'].astype(np.float64)
+    ref = lib.DeconvPlan(psfs, 2, 128, 128, dtype='f64')
+    ref.set_object(np.stack([obj[0], 2 * obj[0]]), 2e5)
+    ref.simulate(seed=9)
+    noisy = ref.measurement() - 12.0                      # a background estimate subtracted: dark pixels go negative
+    assert (noisy < 0).any()
+    ref.set_measurement(noisy)
+    ref.iterate(6)
+    out = {}
+    for name, env in (('default', {}), ('plain', {'RLSTED_SUB_ONE': '0'}), ('per_view', {'RLSTED_FUSE_VIEWS': '0'})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = lib.DeconvPlan(psfs, 2, 128, 128, dtype='f32')
+        for k in env:
+            monkeypatch.delenv(k)
+        plan.set_measurement(noisy)
+        plan.iterate(6)
+        out[name] = plan.estimate()
+    assert np.array_equal(out['default'], out['plain'])
+    assert max_rel(out['default'], ref.estimate()) < 2e-5 and max_rel(out['per_view'], ref.estimate()) < 2e-5
+    clean = lib.DeconvPlan(psfs, 2, 128, 128, dtype='f32')      # without negative pixels the residual form runs (a different rounding path)
+    clean.set_measurement(np.abs(noisy) + 1e-9)
+    clean.iterate(6)
+    monkeypatch.setenv('RLSTED_SUB_ONE', '0')
+    plain = lib.DeconvPlan(psfs, 2, 128, 128, dtype='f32')
+    monkeypatch.delenv('RLSTED_SUB_ONE')
+    plain.set_measurement(np.abs(noisy) + 1e-9)
+    plain.iterate(6)
+    assert not np.array_equal(clean.estimate(), plain.estimate()) and max_rel(clean.estimate(), plain.estimate()) < 2e-5
+
+
 # ---------------------------------------------------------------- BASELINE config 4: the full figure-2 sweep
 def test_config_4_full_figure_2_sweep(lib, golden):
     """4 test objects x 6 doses x 3 scan modes (point-descan, line-descanned, line-rescanned) x 16 seeds = 1152 tasks
@@ -282,6 +343,6 @@ def test_config_5_tolerance_study(lib, tmp_path):
         assert isinstance(study[mode], list), 'study build missing: %r (run __graft_entry__.build())' % (study[mode],)
         q = {r['iteration']: r['max_over_max'] for r in study[mode]}
         assert q[1] > 10 * F32_TOL and q[20] > 100 * F32_TOL, (mode, q)   # three to four orders outside the contract
-    keep = os.path.join(root, 'gpurun_out', 'r03')
+    keep = os.path.join(root, 'gpurun_out', 'r04')
     os.makedirs(keep, exist_ok=True)
     json.dump(study, open(os.path.join(keep, 'tolerance_study_4096.json'), 'w'), indent=1)

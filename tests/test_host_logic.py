@@ -165,3 +165,43 @@ def test_psfs_of_different_shapes_are_embedded_on_a_common_centre():
         assert np.abs(orc.conv_same(x, p) - orc.conv_same(x, q)).max() < 1e-13
     same = [rng.random((1, 5, 5)) for _ in range(2)]
     assert _lib.common_psf_shape(same) is same
+
+
+def test_default_path_kernels_do_not_spill(tmp_path):
+    """DESIGN.md's statements about scratch are checked against the ISA of HEAD.  fft_kernels.hip is
+    compiled device-only for L = 576, 2304 and 4608 (the flags of _build.py) and `.private_segment_fixed_size` is read from
+    the kernel descriptors: 0 for every f32 kernel of the 512 x 512 path, for the split column pass and for the f32 row kernels
+    of the long lengths; the two whole-pass outer column kernels keep the small, documented amounts DESIGN.md section 3 states
+    (L = 2304 on 16-column tiles: <= 96 bytes per lane; L = 4608: <= 24)."""
+    import re
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from rescan_line_sted_amd import _build
+    if not (shutil.which(_build.HIPCC) or os.path.exists(_build.HIPCC)):
+        pytest.skip('no hipcc')
+    src = os.path.join(_build.CSRC, 'fft_kernels.hip')
+
+    def scratch(L):
+        out = str(tmp_path / ('fft_%d.s' % L))
+        subprocess.check_call([_build.HIPCC] + _build.COMMON + _build.DEVICE + _build.FFT_FLAGS +
+                              ['-DRL_CFG_L=%d' % L, '--cuda-device-only', '-S', src, '-o', out], stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+        names = subprocess.run(['c++filt'], input='\n'.join(re.findall(r'\.name:\s+(\S+)', txt)), capture_output=True, text=True).stdout.split('\n')
+        priv = [int(x) for x in re.findall(r'\.private_segment_fixed_size:\s+(\d+)', txt)]
+        return dict(zip(names, priv))
+    with ThreadPoolExecutor(3) as ex:
+        s576, s2304, s4608 = ex.map(scratch, (576, 2304, 4608))
+    f32 = {k: v for k, v in s576.items() if 'float' in k and 'double' not in k}
+    assert len(f32) > 20 and all(v == 0 for v in f32.values()), {k: v for k, v in f32.items() if v}
+    assert all(v == 0 for k, v in s576.items() if 'k_rowpair' in k or 'k_colconv<576, 4, 0' in k)      # the f64 RL loop of the headline size too
+    for table, L, whole_max in ((s2304, 2304, 96), (s4608, 4608, 24)):
+        for k, v in table.items():
+            if 'double' in k:
+                continue                      # (the f64 kernels of the long lengths: DESIGN.md section 8, follow-ups)
+            if 'k_colconv_outer' in k and re.search(r', (true|false), 0>', k):
+                assert v <= whole_max, (k, v)  # the whole pass (single-view plans)
+            elif 'k_colconv_outer' in k and ', true, ' in k:
+                assert v == 0, (k, v)          # the split pass with the real multiplier (what the reference's PSFs run)
+            elif 'k_rowpair' in k or ('k_rowpass' in k and 'true, float, true' not in k):
+                assert v == 0, (k, v)

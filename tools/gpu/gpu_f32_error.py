@@ -28,5 +28,5 @@ plan.bench_cycles(20, 1, seed=1)
 t0 = time.perf_counter(); plan.bench_cycles(20, 10, seed=2); el = time.perf_counter() - t0
 out['frames_per_s'] = 2560 / el
 print(out['frames_per_s'])
-os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r03'), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r03', 'f32err_%s.json' % out['tag']), 'w'))
+os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r04'), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r04', 'f32err_%s.json' % out['tag']), 'w'))

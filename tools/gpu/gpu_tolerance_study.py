@@ -86,7 +86,7 @@ def main():
         subprocess.check_call([sys.executable, os.path.abspath(__file__), '--worker', mode, str(n), str(K), tmp], env=env)
         if mode != 'f64':
             out[mode] = json.load(open(os.path.join(tmp, 'rows_%s.json' % mode)))
-    dest = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'gpurun_out', 'r03', 'tolerance_study_%d.json' % n)
+    dest = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'gpurun_out', 'r04', 'tolerance_study_%d.json' % n)
     os.makedirs(os.path.dirname(os.path.abspath(dest)), exist_ok=True)
     json.dump(out, open(dest, 'w'), indent=1)
     for f in os.listdir(tmp):

@@ -5,7 +5,7 @@
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- \
         python bench.py --steps 1 --warmup 0 --no-cpu-baseline --kernel-reps 2
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- (same)
-    python tools/pmc_traffic.py <fetch counter csv> <write counter csv> <out json> [frames per launch] [size] [views]
+    python tools/pmc_traffic.py <fetch counter csv> <write counter csv> <out json> [frames per launch] [size] [views] [dtype]
 
 Only the most frequent launch shape of each kernel is kept: for the four RL kernels that is
 the slice of the batch the RL loop launches them on (bench.py: roofline.frames_per_launch, pass it
@@ -28,7 +28,7 @@ NAMES = (  # (regex on the kernel name, key in the json); first match wins
     (r'k_colconv_outer<\d+, \d+, \w+, 3>', 'colsplit_FWD'), (r'k_colconv_outer<\d+, \d+, \w+, 4>', 'colsplit_INV'),
     (r'k_colconv_outer<\d+, \d+, \w+, 5>', 'colsplit_INV_SUM'),
     (r'k_colconv<\d+, \d+, 2,', 'colconv_Ht'), (r'k_colconv<\d+, \d+, 1,', 'colconv_H'),
-    (r'k_colconv', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'))
+    (r'k_colconv', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'), (r'k_poisson', 'poisson'))
 
 
 def per_kernel(path, counter):
@@ -61,8 +61,9 @@ def main():
     fl = int(sys.argv[4]) if len(sys.argv) > 4 else 32
     size = int(sys.argv[5]) if len(sys.argv) > 5 else 512
     views = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    dtype = sys.argv[7] if len(sys.argv) > 7 else 'f32'
     res = {'_how': __doc__.strip().split('\n\n')[0] + ' (tools/pmc_traffic.py; FETCH_SIZE doubled, KB = 1024 B)',
-           'frames_per_launch': fl, 'dtype': 'f32', 'shape': [size, size], 'n_psf': views}
+           'frames_per_launch': fl, 'dtype': dtype, 'shape': [size, size], 'n_psf': views}
     for key in sorted(set(fetch) | set(write)):
         f, w = fetch.get(key, 0.0), write.get(key, 0.0)
         # FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: Infinity Cache hits are counted too, so
@@ -80,7 +81,7 @@ def main():
     rl = ('colconv_H', 'rowpass_RATIO', 'colconv_Ht', 'rowpass_UPDATE')
     if all(k in res for k in rl):
         total = sum(res[k]['fabric_bytes_per_launch'] for k in rl)
-        alg = 4 * size * size * (3 * views + 4) * fl
+        alg = (4 if dtype == 'f32' else 8) * size * size * (3 * views + 4) * fl
         res['rl_iteration'] = {'fabric_bytes': total, 'algorithmic_bytes': alg, 'ratio': total / alg,
                                'fabric_MB_per_frame_iteration': total / fl / 1e6}
     json.dump(res, open(sys.argv[3], 'w'), indent=1)
