@@ -405,10 +405,14 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
 // way back -- wait in LDS instead of registers ([value][thread] behind the transform regions: private to the thread, no barrier).
 // The whole pass needs 4 x 10 (8 x 10) values per lane beside a core transform's working set and spills 25-31 dwords per lane
 // at the register budget its residency allows: scratch that streams through HBM (7.4 MB each way per 2048^2 image).
-template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, int PARK = 0, int TWLDS = 0, class Sync>
+// NYC > 0 (round 4): the image has exactly NYC rows, a multiple of 64 M -- every residue class then has NYC / M rows, a multiple
+// of 64, and which rows of a class's tile exist is known at compile time (as colconv_wave_body's NYC: no row compares, no exec
+// branches around the loads and stores; pad columns of the last tile are loaded and stored like the others -- pitch a multiple of C).
+template <class Cfg, int M, int C, typename T, bool REALP = false, int MODE = COL_PER_IMAGE, int PARK = 0, int TWLDS = 0, int NYC = 0, class Sync>
 RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "the core must be a wave-private transform");
     static_assert(M == 2 || M == 4 || M == 8, "outer radix 2, 4 or 8");
+    static_assert(NYC == 0 || (NYC % (64 * M) == 0 && NYC / M <= Cfg::L), "compile-time row count: whole 64-row steps per residue class");
     constexpr int NP = Cfg::NP, Li = Cfg::L, L = M * Li, LP = LdsSlots<Cfg>::value;
     constexpr int NT = 64 * C;
     static_assert((Li * C) % NT == 0, "tile must divide evenly over the workgroup");
@@ -419,10 +423,11 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     constexpr int NV = FL::NBM * FL::R;                  // lane-local register slots of one core transform
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     static_assert(NV <= VMAX, "register slots");
-    const int w = tid / 64, lane = tid % 64;
+    const int w = rl_uniform(tid / 64), lane = tid % 64;
     const int col0 = bx * C, col = col0 + w;
     const bool colok = col < p.kx;
-    const size_t img = spec_image_elems(p.ny, p.pitch);
+    const int ny = NYC > 0 ? NYC : p.ny;
+    const size_t img = spec_image_elems(ny, p.pitch);
     // TWLDS: the core's twiddle table (2016 entries for 576; TWLDS = 2: the (M - 1) x Li outer twiddles behind it too) is copied
     // behind the parking space once per workgroup and read from there: one workgroup per CU exposes every L1 round trip, and 70 % of
     // this body's vector-memory reads are twiddles
@@ -439,46 +444,38 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     }
     LdsView<T, 1, LdsGather<Li>::value> view_lds{lds + w * LP};
 
-    // residue class q of the tile: element e = tid + it*NT <-> (m = e / C, column c = e % C), row M*m + q
+    // residue class q of the tile: element e = tid + it*NT <-> (m = e / C = r_lo + 64 it, column c = e % C), row M*m + q.  One 32-bit
+    // byte offset per thread, the (class, step) part behind a uniform base: `scalar base + lane offset` loads and stores.
     // (fetch_class / park_class: the global loads of a class and their way into LDS, apart -- COL_SPLIT_FWD requests the next
     // class's rows before it transforms the current one)
+    const unsigned c_ = (unsigned)tid % C, r_lo = (unsigned)tid / C;
+    const bool cok = NYC > 0 ? true : (int)(col0 + c_) < p.kx;
+    const unsigned boff = ((unsigned)M * r_lo * (unsigned)p.pitch + (unsigned)col0 + c_) * (unsigned)sizeof(cx<T>);
+    const size_t row_bytes = (size_t)p.pitch * sizeof(cx<T>);
+    auto row_ok = [&](int q, int it) -> bool { return (int)(M * (r_lo + 64 * it)) + q < ny; };   // (NYC: it < NYC / (64 M), whatever q)
     auto fetch_class = [&](const cx<T>* __restrict__ in, int q, cx<T> (&x)[NLD]) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const int row = M * (e / C) + q, c = e % C;
+            const char* sb = reinterpret_cast<const char*>(in) + ((size_t)M * 64 * it + q) * row_bytes;
             x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
+            if (cok && row_ok(q, it)) x[it] = rl_ldg(sync, reinterpret_cast<const cx<T>*>(sb + boff));
         }
     };
     auto park_class = [&](const cx<T> (&x)[NLD]) {
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
-        }
+        for (int it = 0; it < NLD; ++it) lds[c_ * LP + view_lds.nat(r_lo + 64 * it)] = x[it];
     };
     auto load_class = [&](const cx<T>* __restrict__ in, int q) {
         cx<T> x[NLD];
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const int row = M * (e / C) + q, c = e % C;
-            x[it] = mk<T>((T)0, (T)0);
-            if (row < p.ny && col0 + c < p.kx) x[it] = rl_ldg(sync, in + spec_off(row, col0 + c, p.pitch));
-        }
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            lds[(e % C) * LP + view_lds.nat(e / C)] = x[it];
-        }
+        fetch_class(in, q, x);
+        park_class(x);
     };
     auto store_class = [&](cx<T>* __restrict__ out, int q) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int e = tid + it * NT;
-            const int row = M * (e / C) + q, c = e % C;
-            if (row < p.ny && col0 + c < p.kx) out[spec_off(row, col0 + c, p.pitch)] = rl_spec_round(lds[c * LP + view_lds.nat(e / C)], p.qscale);
+            char* sb = reinterpret_cast<char*>(out) + ((size_t)M * 64 * it + q) * row_bytes;
+            if (cok && row_ok(q, it))
+                *reinterpret_cast<cx<T>*>(sb + boff) = rl_spec_round(lds[c_ * LP + view_lds.nat(r_lo + 64 * it)], p.qscale);
         }
     };
     // element index (within the core transform) a lane holds in register slot s; s == NV: the tail element

@@ -184,6 +184,10 @@ struct OuterCol {
     static constexpr int PARK = 0;                       // waiting core results per lane the whole pass keeps in LDS (colconv_outer_body)
     static constexpr int TWLDS = 0;                      // the whole pass reads the core's (1) and the outer (2) twiddles from an LDS copy
     static constexpr int TWLDS_SPLIT = 0;                // the same for the halves of the split pass
+    // float64 (round 4): the whole pass on the same body -- C64 columns (= waves) per workgroup, PARK64 waiting values per lane in
+    // LDS, MIN_WAVES64 waves per SIMD for the register budget; no twiddle copies (the float64 core table is 36 KB), no split pass
+    static constexpr bool value64 = false;
+    static constexpr int C64 = 4, PARK64 = 0, MIN_WAVES64 = 2;
 };
 #ifndef RL_OUTER_2304
 #define RL_OUTER_2304 1
@@ -229,6 +233,17 @@ struct OuterCol<2304> {
     static constexpr int TWLDS = RL_TWLDS_2304;
     static constexpr int TWLDS_SPLIT = RL_TWLDS_SPLIT_2304;   // 2 x (51.3 + 15.8) KB; with the outer table 2 x 80.9 KB would not fit
     static constexpr int PARK = RL_PARK_2304;
+    // float64: 4 x 10 complex doubles per lane wait for the radix-4 step -- 160 registers beside a core transform's ~110 -- so 10 of
+    // them wait in LDS; 4 columns per workgroup (64-byte row segments, as the f32 kernel's 8), two 4-wave workgroups per CU at up to
+    // 256 registers: 2 x (39 + 41) KB.  (rounds 1-3: the workgroup-synchronous (16,16,9) x 144 kernel on 3-column tiles)
+#ifndef RL_OUTER_F64_2304
+#define RL_OUTER_F64_2304 1
+#endif
+#ifndef RL_PARK64_2304
+#define RL_PARK64_2304 10
+#endif
+    static constexpr bool value64 = value && RL_OUTER_F64_2304 != 0;
+    static constexpr int C64 = 4, PARK64 = RL_PARK64_2304, MIN_WAVES64 = 2;
 };
 // 1152 = 2 x 576 (round 3, for the split pass of multi-view plans; as a whole-pass kernel it measured 1.32 -> 1.14 us alone and
 // no gain in the 1024^2 single-view loop in round 2)
@@ -260,6 +275,11 @@ struct OuterCol<1152> {
 #endif
     static constexpr int TWLDS = RL_TWLDS_1152;   // 2 x (51.3 + 15.8 + 4.5) KB
     static constexpr int TWLDS_SPLIT = 2;
+#ifndef RL_OUTER_F64_1152
+#define RL_OUTER_F64_1152 1
+#endif
+    static constexpr bool value64 = value && RL_OUTER_F64_1152 != 0;   // float64: 2 x 10 complex doubles per lane, nothing parked
+    static constexpr int C64 = 4, PARK64 = 0, MIN_WAVES64 = 2;
 };
 // 4608 = 8 x 576 on the same body: 8 x 10 complex values wait in registers.  Measured (us per 512^2-equivalent frame,
 // column kernel alone; whole 20-iteration loop): 3.37 -> 1.96, 4096^2 loop 23.6 -> 17.8 ms per 2 frames.
@@ -284,6 +304,9 @@ struct OuterCol<4608> {
 #define RL_TWLDS_SPLIT_4608 2
 #endif
     static constexpr int TWLDS_SPLIT = RL_TWLDS_SPLIT_4608;
+    // (float64 at 4608: 8 x 10 complex doubles per lane = 320 registers -- the workgroup-synchronous (16,16,18) x 288 kernel stays)
+    static constexpr bool value64 = false;
+    static constexpr int C64 = 2, PARK64 = 0, MIN_WAVES64 = 2;
     static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 57 KB of parking space beside 39 KB of transforms (round 4: 10 values left 40-52 bytes of scratch per lane at HEAD, 14 leave 8-20)
 };
 

@@ -53,6 +53,13 @@ static void rl_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s
     }
 }
 
+template <typename F>
+static hipError_t allow_lds(F* fn, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+
 using CF = CfgFor<RL_CFG_L>;
 using Cfg = CF::Cfg;                               // row kernels
 using CCfg = ColCfgFor<RL_CFG_L>::type;            // column kernels
@@ -60,6 +67,14 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 #define RL_CAT_(a, b) a##b
 #define RL_CAT(a, b) RL_CAT_(a, b)
 #define RL_TABLE_FN RL_CAT(table_, RL_CFG_L)
+
+// Kernels specialised for the 512 x 512 frames of the BASELINE headline (L = 576, f32): row / column counts at compile time.
+#ifndef RL_N512
+#define RL_N512 1
+#endif
+template <typename T>
+constexpr bool kColN512 = RL_N512 != 0 && RL_CFG_L == 576 && sizeof(T) == 4;
+
 
 // NOTE: the transform length is a template parameter of the kernels so that the
 // kernels of different lengths (built in separate translation units) have
@@ -118,11 +133,14 @@ template <class OC>
 constexpr size_t outer_whole_lds_bytes() {
     return ((size_t)OC::CW * LdsSlots<typename OC::Core>::value + (size_t)OC::PARK * 64 * OC::CW + outer_tw_lds_elems<OC>(OC::TWLDS)) * sizeof(cx<float>);
 }
-template <int L, int C, bool REALP, int MODE = COL_PER_IMAGE>
-__global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_outer(const ColParams<float> p) {
+// NYC: the image's row count at compile time (conv_kernels.hpp colconv_outer_body): instantiated for M x 512 rows -- the
+// 1024 / 2048 / 4096-row images whose residue classes are the 512-of-576 case of the core
+template <int L, int C, bool REALP, int MODE = COL_PER_IMAGE, typename T = float, int NYC = 0>
+__global__ void __launch_bounds__(64 * C, (sizeof(T) == 4 ? OuterCol<L>::MIN_WAVES : OuterCol<L>::MIN_WAVES64)) k_colconv_outer(const ColParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevSync s;
     using OC = OuterCol<L>;
+    static_assert(sizeof(T) == 4 || MODE == COL_PER_IMAGE, "float64: the whole pass only");
     unsigned bx = blockIdx.x, by = blockIdx.y;
     const unsigned gx = gridDim.x, gy = gridDim.y, total = gridDim.x * gridDim.y;
     if (total % 8 == 0) {   // XCD-contiguous work order (speed only)
@@ -138,8 +156,28 @@ __global__ void __launch_bounds__(64 * C, OuterCol<L>::MIN_WAVES) k_colconv_oute
             by = w / gx;
         }
     }
-    colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE, (MODE == COL_PER_IMAGE ? OC::PARK : 0), (MODE == COL_PER_IMAGE ? OC::TWLDS : OC::TWLDS_SPLIT)>(p, (int)threadIdx.x, (int)bx, (int)by,
-                                                                                                             reinterpret_cast<cx<float>*>(smem), s);
+    if constexpr (sizeof(T) == 4)
+        colconv_outer_body<typename OC::Core, OC::M, C, float, REALP, MODE, (MODE == COL_PER_IMAGE ? OC::PARK : 0), (MODE == COL_PER_IMAGE ? OC::TWLDS : OC::TWLDS_SPLIT), NYC>(
+            p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<float>*>(smem), s);
+    else
+        colconv_outer_body<typename OC::Core, OC::M, C, double, REALP, COL_PER_IMAGE, OC::PARK64, 0, NYC>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<double>*>(smem), s);
+}
+// launch either the generic kernel or -- M x 512 rows, pitch a multiple of the tile width -- the one with the row count at compile time
+template <int L, int C, bool REALP, int MODE, typename T>
+static void launch_outer(const ColParams<T>& p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    constexpr int NY = 512 * OuterCol<L>::M;
+    if (RL_N512 != 0 && p.ny == NY && p.pitch % C == 0) rl_launch(k_colconv_outer<L, C, REALP, MODE, T, NY>, grid, block, lds, s, p);
+    else rl_launch(k_colconv_outer<L, C, REALP, MODE, T>, grid, block, lds, s, p);
+}
+template <int L, int C, bool REALP, int MODE, typename T>
+static hipError_t allow_outer(size_t lds) {
+    hipError_t e = allow_lds(k_colconv_outer<L, C, REALP, MODE, T>, lds);
+    if (e == hipSuccess) e = allow_lds(k_colconv_outer<L, C, REALP, MODE, T, 512 * OuterCol<L>::M>, lds);
+    return e;
+}
+template <class OC>
+constexpr size_t outer_whole_lds_bytes_f64() {
+    return ((size_t)OC::C64 * LdsSlots<typename OC::Core>::value + (size_t)OC::PARK64 * 64 * OC::C64) * sizeof(cx<double>);
 }
 template <int L>
 static void fill_outer_twiddles(double* out) {
@@ -195,13 +233,6 @@ template <int C, typename T>
 static constexpr size_t col_lds_bytes() {
     return (size_t)C * LdsSlots<CCfg>::value * sizeof(cx<T>);
 }
-
-// Kernels specialised for the 512 x 512 frames of the BASELINE headline (L = 576, f32): row / column counts at compile time.
-#ifndef RL_N512
-#define RL_N512 1
-#endif
-template <typename T>
-constexpr bool kColN512 = RL_N512 != 0 && RL_CFG_L == 576 && sizeof(T) == 4;
 
 template <int C, typename T>
 static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hipStream_t s) {
@@ -313,25 +344,37 @@ static hipError_t launch_col(int dtype, const void* params, unsigned gx, unsigne
             const dim3 grid((unsigned)((p.kx + OC::C - 1) / OC::C), gy), block(64 * OC::C);
             constexpr size_t lds_split = lds + outer_tw_lds_elems<OC>(OC::TWLDS_SPLIT) * sizeof(cx<float>);
             if (p.mode == COL_SPLIT_FWD) {
-                rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, grid, block, lds_split, s, p);
+                launch_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD, float>(p, grid, block, lds_split, s);
                 return hipGetLastError();
             }
             if (p.mode == COL_SPLIT_INV) {
-                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, grid, block, lds_split, s, p);
-                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, grid, block, lds_split, s, p);
+                if (p.psf_hat_re) launch_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV, float>(p, grid, block, lds_split, s);
+                else launch_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV, float>(p, grid, block, lds_split, s);
                 return hipGetLastError();
             }
             if (p.mode == COL_SPLIT_INV_SUM) {
-                if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, grid, block, lds_split, s, p);
-                else rl_launch(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, grid, block, lds_split, s, p);
+                if (p.psf_hat_re) launch_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM, float>(p, grid, block, lds_split, s);
+                else launch_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM, float>(p, grid, block, lds_split, s);
                 return hipGetLastError();
             }
             if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
             // the whole pass has a tile width of its own (OC::CW), its transform regions + parking space + twiddle copies
             constexpr size_t lds_whole = outer_whole_lds_bytes<OC>();
             const dim3 grid_w((unsigned)((p.kx + OC::CW - 1) / OC::CW), gy), block_w(64 * OC::CW);
-            if (p.psf_hat_re) rl_launch(k_colconv_outer<RL_CFG_L, OC::CW, true>, grid_w, block_w, lds_whole, s, p);
-            else rl_launch(k_colconv_outer<RL_CFG_L, OC::CW, false>, grid_w, block_w, lds_whole, s, p);
+            if (p.psf_hat_re) launch_outer<RL_CFG_L, OC::CW, true, COL_PER_IMAGE, float>(p, grid_w, block_w, lds_whole, s);
+            else launch_outer<RL_CFG_L, OC::CW, false, COL_PER_IMAGE, float>(p, grid_w, block_w, lds_whole, s);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (OuterCol<RL_CFG_L>::value64) {
+        if (dtype != DT_F32) {   // float64: the whole pass on the outer-decimation body (per image; multi-view plans launch it per view)
+            using OC = OuterCol<RL_CFG_L>;
+            const ColParams<double>& p = *static_cast<const ColParams<double>*>(params);
+            if (p.mode != COL_PER_IMAGE) return hipErrorInvalidValue;
+            constexpr size_t lds = outer_whole_lds_bytes_f64<OC>();
+            const dim3 grid((unsigned)((p.kx + OC::C64 - 1) / OC::C64), gy), block(64 * OC::C64);
+            if (p.psf_hat_re) launch_outer<RL_CFG_L, OC::C64, true, COL_PER_IMAGE, double>(p, grid, block, lds, s);
+            else launch_outer<RL_CFG_L, OC::C64, false, COL_PER_IMAGE, double>(p, grid, block, lds, s);
             return hipGetLastError();
         }
     }
@@ -354,12 +397,6 @@ constexpr bool kPairRows = WavePrivate<Cfg>::value || (kQ32 == 1 && kQ64 == 1);
 static hipError_t launch_row_pair(int dtype, int mode, const void* params, unsigned gy, hipStream_t s) {
     return dtype == DT_F32 ? launch_row_pair_t<kPairQ32, float>(mode, params, gy, s)
                            : launch_row_pair_t<kQ64, double>(mode, params, gy, s);
-}
-
-template <typename F>
-static hipError_t allow_lds(F* fn, size_t bytes) {
-    if (bytes <= 65536) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 template <int Q, typename T>
@@ -406,14 +443,20 @@ static hipError_t prepare() {
         constexpr size_t lds = (size_t)OC::C * LdsSlots<typename OC::Core>::value * sizeof(cx<float>);
         constexpr size_t lds_whole = outer_whole_lds_bytes<OC>();
         static_assert(lds_whole <= 160 * 1024, "LDS of a CU");
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::CW, true>, lds_whole)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::CW, false>, lds_whole)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::CW, true, COL_PER_IMAGE, float>(lds_whole)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::CW, false, COL_PER_IMAGE, float>(lds_whole)) != hipSuccess) return e;
         constexpr size_t lds_split = lds + outer_tw_lds_elems<OC>(OC::TWLDS_SPLIT) * sizeof(cx<float>);
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD>, lds_split)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV>, lds_split)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV>, lds_split)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM>, lds_split)) != hipSuccess) return e;
-        if ((e = allow_lds(k_colconv_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM>, lds_split)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::C, false, COL_SPLIT_FWD, float>(lds_split)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV, float>(lds_split)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV, float>(lds_split)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::C, true, COL_SPLIT_INV_SUM, float>(lds_split)) != hipSuccess) return e;
+        if ((e = allow_outer<RL_CFG_L, OC::C, false, COL_SPLIT_INV_SUM, float>(lds_split)) != hipSuccess) return e;
+        if constexpr (OC::value64) {
+            constexpr size_t lds64 = outer_whole_lds_bytes_f64<OC>();
+            static_assert(lds64 <= 160 * 1024, "LDS of a CU");
+            if ((e = allow_outer<RL_CFG_L, OC::C64, true, COL_PER_IMAGE, double>(lds64)) != hipSuccess) return e;
+            if ((e = allow_outer<RL_CFG_L, OC::C64, false, COL_PER_IMAGE, double>(lds64)) != hipSuccess) return e;
+        }
     }
     if ((e = prepare_rows<kQ32, float>()) != hipSuccess) return e;
     if ((e = prepare_rows<kQ64, double>()) != hipSuccess) return e;
@@ -439,11 +482,12 @@ struct OuterTw<L, true> {
 const KernelTable* RL_TABLE_FN() {
     constexpr bool OUTER = OuterCol<RL_CFG_L>::value;
     constexpr int WP = WavePrivate<CCfg>::value ? 1 : 0;
-    static const KernelTable t = {Cfg::L, Cfg::T, {OUTER ? OuterCol<RL_CFG_L>::C : kC32, kC64}, {kQ32, kQ64},
-                                  {OUTER ? 1 : WP, WP}, {OUTER ? 0 : 3 * WP, 3 * WP},
+    constexpr bool OUTER64 = OuterCol<RL_CFG_L>::value64;   // float64 column pass on the outer-decimation body too
+    static const KernelTable t = {Cfg::L, Cfg::T, {OUTER ? OuterCol<RL_CFG_L>::C : kC32, OUTER64 ? OuterCol<RL_CFG_L>::C64 : kC64}, {kQ32, kQ64},
+                                  {OUTER ? 1 : WP, OUTER64 ? 1 : WP}, {OUTER ? 0 : 3 * WP, OUTER64 ? 0 : 3 * WP},
                                   PassTw<Cfg, false, 0>::TOTAL, fill_pass_twiddles<Cfg>,
-                                  {OuterTw<RL_CFG_L, OUTER>::count, PassTw<CCfg, false, 0>::TOTAL},
-                                  {OuterTw<RL_CFG_L, OUTER>::fill, fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,
+                                  {OuterTw<RL_CFG_L, OUTER>::count, OUTER64 ? OuterTw<RL_CFG_L, OUTER64>::count : PassTw<CCfg, false, 0>::TOTAL},
+                                  {OuterTw<RL_CFG_L, OUTER>::fill, OUTER64 ? OuterTw<RL_CFG_L, OUTER64>::fill : fill_pass_twiddles<CCfg>}, launch_col, launch_row, prepare,
                                   kPairRows ? launch_row_pair : nullptr, OuterTw<RL_CFG_L, OUTER>::split_tile};
     return &t;
 }

@@ -409,6 +409,7 @@ struct rl_deconv {
     // The split column pass (conv_kernels.hpp COL_SPLIT_*; f32 multi-view plans on the long column transforms): H transforms a frame's
     // spectrum once for its V views, H_t sums the views' products before one inverse transform (RLSTED_COL_SPLIT=0: A/B knob)
     bool split_wanted = true;
+    bool split_h = true;     // H through the split pass too (RLSTED_SPLIT_H=0: H_t only -- measured in round 4)
     bool col_split() const { return split_wanted && dtype == RL_F32 && V > 1 && ty->split_tile_elems > 0; }
     size_t n_spec_x() const { return (size_t)((kx + ty->C[RL_F32] - 1) / ty->C[RL_F32]) * ty->split_tile_elems; }
     // one half of the split pass over `images` launch rows
@@ -734,7 +735,8 @@ struct rl_deconv {
             if (first) {
                 RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), spec_ones, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr, nullptr, -1, V));
             } else {
-                RL_TRY(col_split_pass(sa, sb, sx, nf, COL_H));
+                if (split_h) RL_TRY(col_split_pass(sa, sb, sx, nf, COL_H));
+                else RL_TRY(col(sa, sb, nf, true));          // (RLSTED_SPLIT_H=0: V whole-pass launches, nothing parked on this side)
                 RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));
             }
             if (fuse_views) {
@@ -1284,6 +1286,9 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
         if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
     }
     if (getenv("RLSTED_COL_SPLIT")) h->split_wanted = atoi(getenv("RLSTED_COL_SPLIT")) != 0;
+    // H through the split pass from three views on: with two the forward half saved (1 + V against 2 V column transforms) does not pay
+    // for parking the spectrum -- measured, 2048^2: 2 views 429 (split) against 449 frames/s, 4 views 269 against 258
+    h->split_h = getenv("RLSTED_SPLIT_H") ? atoi(getenv("RLSTED_SPLIT_H")) != 0 : n_psf >= 3;
     if (getenv("RLSTED_COL_MULTI")) h->col_multi = atoi(getenv("RLSTED_COL_MULTI")) != 0;
     h->fuse_views = getenv("RLSTED_FUSE_VIEWS") ? atoi(getenv("RLSTED_FUSE_VIEWS")) != 0 : (dtype == RL_F32);
     h->exact_norm = getenv("RLSTED_EXACT_NORM") ? atoi(getenv("RLSTED_EXACT_NORM")) != 0 : (dtype == RL_F32);

@@ -58,11 +58,8 @@ class Deconvolver:
         self.device = _DEFAULT_DEVICE if device is None else device
         self.rng = rng
         for p in self.psfs:
-            if np.ndim(p) != 3 or np.shape(p)[0] != 1:
-                # the reference's fftconvolve is n-dimensional (ref:574,586): a PSF with depth couples the z slices.
-                # Every PSF the reference's scripts build is (1, n, n); INTEGRATION.md section 4.
-                raise NotImplementedError(
-                    'device path supports 2-D PSFs of shape (1, py, px); got %s' % (np.shape(p),))
+            if np.ndim(p) != 3:
+                raise NotImplementedError('PSFs must be 3-D arrays (pz, py, px); got %s' % (np.shape(p),))
         self._plan = None
         self._aux_plans = {}            # H / H_t on shapes other than the data's (the RL state stays untouched)
         self._estimate = None
@@ -71,6 +68,26 @@ class Deconvolver:
         return None
 
     # ---- device plan management -------------------------------------------
+    def _plan_psfs(self, nz):
+        """The 2-D PSFs of a device plan for data of nz slices.  The reference's fftconvolve is n-dimensional (ref:574,586):
+        out[z] = sum_k conv2d(x[z + c - k], psf[k]), c = (pz - 1) // 2 ('same' along z too).  Every PSF its scripts build is
+        (1, n, n) -- axis 0 is then a batch of independent slices, which is what a plan's frames are.  A PSF with depth
+        couples the slices; on ONE slice only its plane k = c meets the data, so the plan takes that plane.  More than one
+        slice with such a PSF is not built."""
+        out = []
+        for p in self.psfs:
+            pz = np.shape(p)[0]
+            if pz == 1:
+                out.append(p)
+            elif nz == 1:
+                c = (pz - 1) // 2
+                out.append(np.asarray(p)[c:c + 1])
+            else:
+                raise NotImplementedError(
+                    'a PSF with depth (shape %s) couples the %d z slices of the data: the device path convolves slice by slice '
+                    '(PSFs of shape (1, py, px), or single-slice data)' % (np.shape(p), nz))
+        return out
+
     def _plan_for(self, shape):
         """The plan that holds the data (object, measurement, estimate)."""
         nz, ny, nx = shape
@@ -78,7 +95,7 @@ class Deconvolver:
         if p is None or (p.B, p.ny, p.nx) != (nz, ny, nx):
             if p is not None and self._estimate_stale:      # keep what the old plan computed
                 self._estimate, self._estimate_stale = p.estimate(), False
-            self._plan = DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)
+            self._plan = DeconvPlan(self._plan_psfs(nz), nz, ny, nx, dtype=self.dtype, device=self.device)
             self._measurement_on_device = False             # the host copy is pushed again when needed
             self._estimate_push = self._estimate is not None and np.shape(self._estimate) == (nz, ny, nx)
             if hasattr(self, 'H_t_normalization'):
@@ -96,7 +113,7 @@ class Deconvolver:
             return p
         key = (nz, ny, nx)
         if key not in self._aux_plans:
-            self._aux_plans = {key: DeconvPlan(self.psfs, nz, ny, nx, dtype=self.dtype, device=self.device)}
+            self._aux_plans = {key: DeconvPlan(self._plan_psfs(nz), nz, ny, nx, dtype=self.dtype, device=self.device)}
         return self._aux_plans[key]
 
     # ---- data ---------------------------------------------------------------

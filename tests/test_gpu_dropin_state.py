@@ -191,5 +191,26 @@ def test_views_of_different_psf_shapes(st, tmp_path):
         d.iterate()
         o.iterate()
     assert max_rel(d.estimate, o.estimate) < 1e-10
-    with pytest.raises(NotImplementedError):                              # PSFs with depth couple the z slices: not on the device
-        st.Deconvolver([rng.random((3, 5, 5))], str(tmp_path) + '/', verbose=False)
+
+
+def test_psfs_with_depth(st, tmp_path):
+    """The reference's fftconvolve is n-dimensional (ref:574,586): out[z] = sum_k conv2d(x[z + c - k], psf[k]), c = (pz - 1) // 2.
+    On single-slice data only the PSF's plane k = c meets the data -- the device plan takes that plane and the drop-in equals the
+    oracle's 3-D convolutions (odd and even depths); data of several slices with such a PSF is not built and says so."""
+    rng = np.random.default_rng(13)
+    x = rng.random((1, 36, 44)) * 20
+    for pz in (3, 4):
+        psfs = [rng.random((pz, 7, 9)) + 0.01, rng.random((1, 5, 5)) + 0.01]
+        d = st.Deconvolver(psfs, str(tmp_path) + '/', verbose=False)
+        o = orc.Deconvolver(psfs)
+        for a, b in zip(d.H(x), o.H(x)):
+            assert max_rel(a, b) < 1e-12
+        d.create_data_from_object(x, 1e6, random_seed=2)
+        o.create_data_from_object(x, 1e6, noisy_measurement=d.noisy_measurement)
+        for _ in range(5):
+            d.iterate()
+            o.iterate()
+        assert max_rel(d.estimate, o.estimate) < 1e-10
+    d = st.Deconvolver([rng.random((3, 5, 5))], str(tmp_path) + '/', verbose=False)
+    with pytest.raises(NotImplementedError, match='couples the 2 z slices'):
+        d.H(rng.random((2, 20, 20)))

@@ -1,5 +1,5 @@
 """Manual helper (not a test): slice size (RLSTED_CHUNK_MB) x lanes (RLSTED_LANES) sweep of the headline workload in one process.
-    python3 tools/gpu/sweep_slices.py [size] [views] [batch]
+    python3 tools/gpu/sweep_slices.py [size] [views] [batch] [chunk MB list, comma separated]
 """
 import os
 import sys
@@ -17,7 +17,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_fig2_psfs.npz'))
 psfs = [g['2p0x_lr/point_sted_psf'][0]] if V == 1 else [p[None] for p in g['2p0x_lr/line_sted_psfs'][:V, 0]]
 obj = np.random.default_rng(1234).random((n, n)) * 255
-combos = [(l, c) for l in (1, 2, 3, 4) for c in (27, 54, 80, 108, 160, 216)]
+chunks = [int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [27, 54, 80, 108, 160, 216]
+combos = [(l, c) for l in (1, 2, 3, 4) for c in chunks]
 res = {}
 for rnd in range(2):
     for lanes, chunk in combos:

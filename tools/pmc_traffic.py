@@ -25,8 +25,8 @@ NAMES = (  # (regex on the kernel name, key in the json); first match wins
     (r'k_rowpass<\d+, \d+, 2,', 'rowpass_RATIO'), (r'k_rowpass<\d+, \d+, 3,', 'rowpass_UPDATE'),
     (r'k_rowpass<\d+, \d+, 4,', 'rowpass_ADJ'),
     # the split column pass of multi-view plans on the long transforms (conv_kernels.hpp COL_SPLIT_FWD / _INV / _INV_SUM)
-    (r'k_colconv_outer<\d+, \d+, \w+, 3>', 'colsplit_FWD'), (r'k_colconv_outer<\d+, \d+, \w+, 4>', 'colsplit_INV'),
-    (r'k_colconv_outer<\d+, \d+, \w+, 5>', 'colsplit_INV_SUM'),
+    (r'k_colconv_outer<\d+, \d+, \w+, 3[,>]', 'colsplit_FWD'), (r'k_colconv_outer<\d+, \d+, \w+, 4[,>]', 'colsplit_INV'),
+    (r'k_colconv_outer<\d+, \d+, \w+, 5[,>]', 'colsplit_INV_SUM'),
     (r'k_colconv<\d+, \d+, 2,', 'colconv_Ht'), (r'k_colconv<\d+, \d+, 1,', 'colconv_H'),
     (r'k_colconv', 'colconv'), (r'k_poisson_fast', 'poisson_fast'), (r'k_poisson_slow', 'poisson_slow'), (r'k_poisson', 'poisson'))
 
