@@ -214,7 +214,7 @@ enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
 // does not inherit the register footprint of the multi-view loops.
 // (A twiddle copy in LDS like colconv_outer_body's was tried for the fused multi-view modes -- two workgroups per CU, room for it:
 // 512^2 x 4 views 5941 -> 5973 frames/s, noise.  These kernels wait for the vector ALU, not for L1.)
-// NYC > 0 (round 4; COL_PER_IMAGE, single-view launches): the image has exactly NYC rows, a multiple of 64 -- which rows of the
+// NYC > 0 (round 4; COL_PER_IMAGE launches of single-view plans, and the fused multi-view modes): the image has exactly NYC rows, a multiple of 64 -- which rows of the
 // tile exist is then known at compile time (no row compares, no exec branches around the loads and stores; the rows that do
 // not exist are written to LDS as constants), and the pad columns kx .. pitch - 1 of the last tile are loaded and stored like
 // the others (pitch is a multiple of C: in bounds; nobody reads them as data).
@@ -222,7 +222,7 @@ enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
 template <class Cfg, int C, int MODE, typename T, bool REALP = false, int NYC = 0, int CT = 0, class Sync>
 RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "wave-private body needs one wave per transform");
-    static_assert(NYC == 0 || (MODE == COL_PER_IMAGE && NYC % 64 == 0 && NYC <= Cfg::L), "compile-time row count");
+    static_assert(NYC == 0 || (NYC % 64 == 0 && NYC <= Cfg::L), "compile-time row count");
     constexpr int NP = Cfg::NP, L = Cfg::L, LP = LdsSlots<Cfg>::value;
     constexpr int VMAX = CfgRegs<Cfg>::VMAX;
     constexpr int NT = 64 * C;
@@ -366,7 +366,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
             if (colok) {
                 cx<T> v[VMAX];
                 cx<T> tl = mk<T>((T)0, (T)0);
-                run_passes<Cfg, false, 0, false>(v, tl, lane, view_lds, tw, sync);
+                run_passes<Cfg, false, 0, false, CT>(v, tl, lane, view_lds, tw, sync);
                 multiply(v, tl, view);
 #pragma unroll
                 for (int i = 0; i < FL::NBM * FL::R; ++i) acc[i] = acc[i] + v[i];

@@ -252,6 +252,14 @@ static hipError_t launch_col_t(const void* params, unsigned gx, unsigned gy, hip
                 return hipGetLastError();
             }
         }
+        if constexpr (kColN512<T>) {   // the fused multi-view modes on 512-row images (real multiplier: what the reference's PSFs run)
+            if (p.psf_hat_re && p.ny == 512 && p.pitch % C == 0 && (p.mode == COL_H_MULTI || p.mode == COL_HT_SUM)) {
+                if (p.mode == COL_H_MULTI) rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T, true, 512>, grid, block, lds, s, p);
+                else if (p.residual && RL_CT_RESIDUAL) rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T, true, 512, 1>, grid, block, lds, s, p);   // spectra of `ratio - 1`
+                else rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T, true, 512>, grid, block, lds, s, p);
+                return hipGetLastError();
+            }
+        }
         if (p.psf_hat_re) {   // real PSF spectrum
             if (p.mode == COL_H_MULTI) rl_launch(k_colconv<RL_CFG_L, C, COL_H_MULTI, T, true>, grid, block, lds, s, p);
             else if (p.mode == COL_HT_SUM) rl_launch(k_colconv<RL_CFG_L, C, COL_HT_SUM, T, true>, grid, block, lds, s, p);

@@ -92,6 +92,7 @@ struct rl_deconv {
     // through rl_deconv_set_measurement) therefore runs the plain arithmetic with the per-view clamp; so does RLSTED_FUSE_VIEWS=0,
     // the switch that asks for the reference's per-view clamp.
     bool meas_negative = false;
+    bool in_rl_loop = false;   // set by iterate_chunk: only there do the H_t column launches carry `ratio - 1` (rl_adjoint's input is an image)
     bool sub() const { return sub_one && !(V > 1 && meas_negative); }
     void* obj = nullptr;       // [B][ny][nx]
     void* noiseless = nullptr; // [B*V][ny][nx]
@@ -243,7 +244,7 @@ struct rl_deconv {
         p.mode = V == 1 ? COL_PER_IMAGE : (kind == COL_H ? COL_H_MULTI : COL_HT_SUM);
         p.in_sb = 1; p.in_sv = 0;
         p.images = pairs; p.order = col_order;
-        p.residual = (kind != COL_H && sub()) ? 1 : 0;   // H_t of a `ratio - 1` plan: the spectrum of a residual
+        p.residual = (kind != COL_H && sub() && in_rl_loop) ? 1 : 0;   // H_t inside a `ratio - 1` iteration: the spectrum of a residual
         const int C = ty->C[dtype];
         TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
         HIP_TRY(ty->launch_col(dtype, &p, (unsigned)((lx + C - 1) / C), (unsigned)pairs, cur()));
@@ -486,6 +487,7 @@ struct rl_deconv {
         const unsigned gx = (unsigned)((kx + C - 1) / C);
         p.images = (int)gy;
         p.order = col_order;
+        p.residual = (kind != COL_H && sub() && in_rl_loop) ? 1 : 0;   // H_t inside a `ratio - 1` iteration: the spectra of residuals
         {
             TimedScope t(this, kind == COL_H ? TK_COL_H : TK_COL_HT);
             HIP_TRY(ty->launch_col(dtype, &p, gx, gy, cur()));
@@ -696,6 +698,11 @@ struct rl_deconv {
             float& q; float keep;
             ~ScaleGuard() { q = keep; }
         } scale_guard{q_ratio, q_ratio};
+        struct LoopGuard {
+            bool& f;
+            ~LoopGuard() { f = false; }
+        } loop_guard{in_rl_loop};
+        in_rl_loop = true;
         if (from_ones) q_ratio = q_est;
         if (sep) return sep_iterate(f0, nf);
         if (pair) {   // the whole iteration in the pair spectra, in place
