@@ -129,13 +129,13 @@ def test_deconvolver_surface_matches_reference(tmp_path):
 
 
 def test_pmc_traffic_json_is_what_the_tool_makes_of_the_committed_counter_files(tmp_path):
-    """profiles/r03/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from the committed rocprofv3
+    """profiles/r04/pmc_traffic.json (read by bench.py for roofline.traffic) is reproducible from the committed rocprofv3
     counter files with tools/pmc_traffic.py; its per-iteration sum is what DESIGN.md quotes (12.9 MB per frame-iteration,
     1.76x the algorithmic bytes)."""
     import json
     import subprocess
     import sys
-    prof = os.path.join(ROOT, 'profiles', 'r03')
+    prof = os.path.join(ROOT, 'profiles', 'r04')
     committed = json.load(open(os.path.join(prof, 'pmc_traffic.json')))
     out = tmp_path / 'traffic.json'
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'),
