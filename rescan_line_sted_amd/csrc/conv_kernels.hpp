@@ -202,9 +202,6 @@ RL_HD void colconv_body(const ColParams<T>& p, int tid, int bx, int by, cx<T>* l
 //                  in the Fourier domain and inverse transformed once -> output image frame
 //                  (H_t, ref:584-588, with the per-view clamp replaced by one clamp of the sum:
 //                  identical in exact arithmetic, see DESIGN.md "fused views")
-#ifndef RL_SPLIT_PREFETCH
-#define RL_SPLIT_PREFETCH 1
-#endif
 enum ColMode { COL_PER_IMAGE = 0, COL_H_MULTI = 1, COL_HT_SUM = 2,
                // the split column pass of colconv_outer_body (round 3): forward half -> column spectra in register-slot order,
                // inverse half from there -- one image per launch row, or the V views of a frame summed
@@ -488,7 +485,7 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     using Regs = cx<T>[M][NV + 1];   // [q][slot]; slot NV = tail element (unused when the core has none)
     // Y <- the M core transforms of the residue classes of image `in`; `first`: no workgroup is still reading LDS
     auto forward_classes = [&](const cx<T>* __restrict__ in, Regs& Y, bool first) {
-        if constexpr (MODE == COL_SPLIT_FWD && RL_SPLIT_PREFETCH) {   // (the same in the whole kernel: measured neutral, +-1 %)
+        if constexpr (MODE == COL_SPLIT_FWD) {   // (the same in the whole kernel: measured neutral, +-1 %)
             cx<T> x[NLD];
             fetch_class(in, 0, x);
 #pragma unroll
@@ -1184,9 +1181,6 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 // pass leaves: that is what lets FFT -> pointwise -> IFFT chain in the column kernel) and stored from it.
 // Wave-private lengths; an odd frame count leaves the last pair's imaginary part empty.  Multi-view plans: ROW_RATIO runs
 // per (pair, view) image (p.V views), ROW_FWD / ROW_UPDATE on the pair's single (view-summed) spectrum with p.V = 1.
-#ifndef RL_PAIR_NRM_EARLY
-#define RL_PAIR_NRM_EARLY 1
-#endif
 #ifndef RL_CT_RESIDUAL
 #define RL_CT_RESIDUAL 1      // compact twiddles in the transforms that carry `ratio - 1` (specialised 512-pixel kernels)
 #endif
@@ -1229,7 +1223,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     };
 
     // operands of the pointwise stage: measurement / estimate requested ahead of the inverse transform, the normaliser
-    // (an L2 hit: one image shared by all frames) ahead of it too or right behind it (RL_PAIR_NRM_EARLY: registers against waits)
+    // (an L2 hit: one image shared by all frames) ahead of it too or right behind it (1: registers against waits)
     cx<T> pre[NB * R];
     T nrm[MODE == ROW_UPDATE ? NB * R : 1];
     {
@@ -1255,7 +1249,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 }
         }
     };
-    if constexpr (RL_PAIR_NRM_EARLY != 0) request_norm();
+    request_norm();   // (ahead of the inverse transform: requesting it behind the transform saved 8 registers and measured slower)
     cx<T> v[VMAX];
     cx<T> tl = mk<T>((T)0, (T)0);
     if constexpr (MODE != ROW_FWD) {
@@ -1271,7 +1265,6 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         // (SUBC == 1: the update's inverse transform carries H_t(ratio - 1), the ratio kernel's forward transform ratio - 1)
         run_passes<Cfg, true, 0, true, (SUBC == 1 && MODE == ROW_UPDATE) ? RL_CT_RESIDUAL : 0>(v, tl, t, view_lds, p.tw, sync);
     }
-    if constexpr (RL_PAIR_NRM_EARLY == 0) request_norm();
 #pragma unroll
     for (int s = 0; s < NB * R; ++s) {
         const int nb = s / R, r = s % R;

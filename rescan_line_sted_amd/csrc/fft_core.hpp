@@ -361,31 +361,20 @@ inline void fill_pass_twiddles(double* out) {
     }
 }
 
-#ifndef RL_COMPACT_TW
-#define RL_COMPACT_TW 1
-#endif
-#ifndef RL_COMPACT_TW_DEPTH1
-#define RL_COMPACT_TW_DEPTH1 1     // one product deep (6 of 15 loaded) instead of up to three (4 of 15): the same speed, less rounding
-#endif
-#ifndef RL_COMPACT_TW_BASE
-#define RL_COMPACT_TW_BASE 2      // (4 -- only w^1 and w^4 loaded for a radix-16 pass -- measured the same speed: 2 keeps the products shallower)
-#endif
-#ifndef RL_COMPACT_TW_F64
-#define RL_COMPACT_TW_F64 1      // f64 too (tables twice the size): 2048^2 253 -> 311 frames/s, x 4 views 74 -> 90.5, 4096^2 46.4 -> 53.1
-#endif
-#ifndef RL_COMPACT_TW_SMALL_L
-#define RL_COMPACT_TW_SMALL_L 256     // ... and the short lengths (64, 192, 256: the 128^2 configs): 128^2 point 208 -> 217 k frames/s, x 4 views 62.8 -> 64.7 k,
-                                      // every accuracy test of those sizes unchanged
-#endif
-#ifndef RL_COMPACT_TW_MIN_L_F64
-#define RL_COMPACT_TW_MIN_L_F64 576
-#endif
-#ifndef RL_COMPACT_TW_MIN_L
-#define RL_COMPACT_TW_MIN_L 1152     // f32: not the wave-private 576, although it is 3-4 % faster there too (512^2 point 18961 -> 19554 frames/s,
-                                     // three alternating runs each): the pixelwise error of two config-2 cases goes from 2.3e-4 to 3.2e-4
-                                     // (3.8e-4 with the deeper products; 3.04e-4 and +2 % with only w^5 and w^7 of a radix-8 butterfly as products),
-                                     // past the 3e-4 tests/test_gpu_configs.py asserts.  f64 (below): 9448 -> 9600
-#endif
+// Compact twiddles (round 3; conditions fixed in round 4 -- the switches that chose them are gone, their measurements stay here):
+// a pass of radix > 4 loads only w^1, w^2, w^3 and the multiples of four w^4, w^8, w^12 of a butterfly's twiddle (rows of the
+// SAME table: 6/15 of a radix-16 table's lines are ever touched) and forms each of the others as ONE product of two loaded values
+// (loading only the powers of two, products up to three deep, measured the same speed with more rounding; base 4 -- only w^1 and w^4
+// of a radix-16 pass -- the same speed with deeper products).  Where:
+//   f32  L >= 1152 (the long transforms' 69 KB tables do not stay in L1: 2048^2 point 779 -> 879 frames/s) and L <= 256 (the 128^2
+//        configs: 208 -> 217 k frames/s); NOT the wave-private 576 by default -- 3-4 % faster there too, but it is the
+//        estimate-carrying transforms' rounding that the pixelwise error measures -- except on the transforms that carry
+//        `ratio - 1` (CT below, round 4)
+//   f64  L >= 576 and L <= 256 (tables twice the size: 2048^2 253 -> 311 frames/s, 512^2 9448 -> 9600)
+template <int L, typename T>
+constexpr bool compact_twiddles_default() {
+    return L <= 256 || L >= (sizeof(T) == 4 ? 1152 : 576);
+}
 // CT = 1: the compact form whatever the length (round 4: the transforms of an RL iteration that carry `ratio - 1`, a residual
 // of the size of the shot noise -- their rounding error is proportional to what they carry, so the products' extra rounding is
 // of no consequence there, while the transforms that carry the estimate keep their full tables).
@@ -399,26 +388,14 @@ RL_HD void pass_compute(cx<T>* v, int t, const cx<T>* __restrict__ tw) {
         if (j < PI::NBF) {
             if constexpr (PI::NS > 1) {
                 const cx<T>* __restrict__ w = tw + PassTw<Cfg, INV, P>::OFFSET + j;
-                // COMPACT (the long f32 transforms, whose tables -- 69 KB at L = 2304 -- do not stay in L1: 53 of the row kernels'
-                // 79 vector loads are twiddles, 2x the data's bytes out of L2; all lanes reading ONE entry instead measured 2048^2
-                // +7 ... +11 %): only the powers w^1, w^2, w^4, w^8 of a butterfly's twiddle are loaded (rows r = 1, 2, 4, 8 of the
-                // same table: 4/15 of its lines are ever touched), the others are products of two of those (<= 3 roundings deep)
-                constexpr bool COMPACT = RL_COMPACT_TW != 0 && (sizeof(T) == 4 || RL_COMPACT_TW_F64 != 0) && R > 4 &&
-                                         (CT != 0 || Cfg::L >= (sizeof(T) == 4 ? RL_COMPACT_TW_MIN_L : RL_COMPACT_TW_MIN_L_F64) || Cfg::L <= RL_COMPACT_TW_SMALL_L);
+                constexpr bool COMPACT = R > 4 && (CT != 0 || compact_twiddles_default<Cfg::L, T>());
                 if constexpr (COMPACT) {
                     cx<T> wp[R];
 #pragma unroll
                     for (int r = 1; r < R; ++r) {
-#if RL_COMPACT_TW_DEPTH1
                         // loaded: r < 4 and the multiples of 4; every other one is ONE product of two loaded values
                         const bool loaded = r < 4 || r % 4 == 0;
                         wp[r] = loaded ? w[(r - 1) * PI::NBF] : cmul(wp[r - r % 4], wp[r % 4]);
-#else
-                        int hb = 1;
-                        while (RL_COMPACT_TW_BASE * hb <= r) hb *= RL_COMPACT_TW_BASE;     // largest loaded power <= r
-                        const int q = r / hb * hb;                                         // (base 2: q == hb)
-                        wp[r] = r == hb ? w[(r - 1) * PI::NBF] : (q == r ? cmul(wp[q - hb], wp[hb]) : cmul(wp[q], wp[r - q]));
-#endif
                         v[nb * R + r] = cmul(v[nb * R + r], wp[r]);
                     }
                 } else {

@@ -18,15 +18,6 @@
 #endif
 // (waves per SIMD requested for the long row kernels: 6 / 5 for RATIO / UPDATE -- five or six workgroups per CU instead of four --
 // measured 2048^2 point 781 -> 712 frames/s, 4 views 247 -> 216: left to the compiler)
-#ifndef RL_ROWL_RATIO_WAVES
-#define RL_ROWL_RATIO_WAVES 1
-#endif
-#ifndef RL_ROWL_UPD_WAVES
-#define RL_ROWL_UPD_WAVES 1
-#endif
-#ifndef RL_ROW_LEAN
-#define RL_ROW_LEAN 1
-#endif
 // waves/SIMD requested for the f32 per-image column kernel: 6 = three 8-wave workgroups per CU
 // (80 VGPRs, no spills; 3 x 51 KB LDS), whose load / transform / store phases overlap better than
 // two (+1.7 % end to end).  The multi-view modes spill under that bound and keep 1.
@@ -197,8 +188,8 @@ static void fill_outer_twiddles(double* out) {
 template <int L, int MODE, bool ONEV, typename T>
 constexpr int row_min_waves() {
     if (sizeof(T) == 4 && !WavePrivate<typename CfgFor<L>::Cfg>::value) {   // the long lengths (256 threads per transform)
-        if (MODE == ROW_RATIO) return RL_ROWL_RATIO_WAVES;
-        if (MODE == ROW_UPDATE && ONEV) return RL_ROWL_UPD_WAVES;
+        if (MODE == ROW_RATIO) return 1;
+        if (MODE == ROW_UPDATE && ONEV) return 1;
         return 1;
     }
     if (sizeof(T) != 4) return 1;
@@ -218,7 +209,7 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, 
     const unsigned bx = blockIdx.x, by = blockIdx.y;
     // single-view RL modes of the wave-private lengths: the lean item code (scalar row bases,
     // unconditional loads).  RATIO treats every (frame, view) image on its own, so it always qualifies.
-    constexpr bool LEAN = RL_ROW_LEAN && !PRESUM && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
+    constexpr bool LEAN = !PRESUM && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
     if constexpr (LEAN)
         rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
