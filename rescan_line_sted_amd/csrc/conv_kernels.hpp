@@ -22,6 +22,10 @@
 #pragma once
 #include "fft_core.hpp"
 
+#ifndef RL_CT_RESIDUAL
+#define RL_CT_RESIDUAL 1      // compact twiddles in the transforms that carry `ratio - 1` (kernels with `sub_one` at compile time)
+#endif
+
 namespace rl {
 
 // a / b.  float: hardware reciprocal (v_rcp_f32, <= 1 ulp) times a -- the f32 plans
@@ -805,9 +809,12 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     // starts, so their HBM latency hides behind it (measurement for ROW_RATIO, the
     // current estimate for ROW_UPDATE).
     constexpr bool PREFETCH = (MODE == ROW_RATIO || MODE == ROW_UPDATE);
+    // (float64 at L = 4608: a 576-thread workgroup is 9 waves, so a lane has at most 168 registers, and 8 complex doubles held
+    // through the inverse transform were 124-460 bytes of scratch per lane: there the operands are requested behind the transform)
+    constexpr bool EARLY = !(sizeof(T) == 8 && L >= 4608);
     cx<T> pre[PREFETCH ? NB * R : 1];
     rl_stamp(sync, 0);
-    if constexpr (PREFETCH) {
+    auto request_operands = [&] {
         const T* __restrict__ src = (MODE == ROW_RATIO ? p.src : p.dst) + (size_t)by * rimg;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -822,7 +829,8 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 pre[nb * R + r] = m;
             }
         }
-    }
+    };
+    if constexpr (PREFETCH && EARLY) request_operands();
 
     if constexpr (MODE != ROW_FWD) {
         constexpr bool MULTI = (MODE == ROW_UPDATE || MODE == ROW_ADJ);
@@ -899,6 +907,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         }
     }
 
+    if constexpr (PREFETCH && !EARLY) request_operands();
     // ROW_UPDATE / ROW_ADJ: every normaliser value is requested before the first store of the
     // pointwise stage.  (vmcnt retires in order: a load issued behind a store cannot be
     // waited for without waiting for that store, and the compiler may not move the loads up
@@ -1041,7 +1050,9 @@ struct RowSpectra {
 // One row pair of ROW_RATIO / ROW_UPDATE (single view) for a wave: spectra `in` (already
 // requested) -> pack -> inverse -> pointwise -> forward -> split -> store.  by, r0: image and first
 // row (wave uniform); t: lane; tw: twiddle table.
-template <class Cfg, int MODE, typename T, class View, class Sync>
+// NXC / SUBC as rowpair_body's (round 4): the row length (a multiple of 64) and `sub_one` at compile time -- no per-pixel
+// selects; SUBC == 1 also puts compact twiddles on the transform that carries `ratio - 1`.
+template <class Cfg, int MODE, typename T, int NXC = 0, int SUBC = -1, class View, class Sync>
 RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectra<Cfg, T>& in, View view_lds, const cx<T>* tw, Sync& sync) {
     static_assert(MODE == ROW_RATIO || MODE == ROW_UPDATE, "RL modes only");
     constexpr int NP = Cfg::NP, L = Cfg::L;
@@ -1053,18 +1064,20 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
     static_assert(!F0::TAIL, "the pass that touches the images must be lane-local");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
     constexpr int NPK = RowSpectra<Cfg, T>::NPK;
-    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * p.nx;
+    static_assert(NXC == 0 || (NXC % 64 == 0 && NXC <= L && NB == 1 && NBF == 64), "compile-time row length: whole 64-pixel slots");
+    const int nx = NXC > 0 ? NXC : p.nx;
+    const size_t simg = spec_image_elems(p.ny, p.pitch), rimg = (size_t)p.ny * nx;
     const int tl_ = (int)t;
     const int r1 = r0 + 1;
     const bool ok1 = r1 < p.ny;
     rl_stamp(sync, 0);
     // operands of the pointwise stage, requested ahead of the inverse transform: measurement (ROW_RATIO) / current estimate (ROW_UPDATE)
     cx<T> pre[NB * R];
-    T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * p.nx;
-    T* __restrict__ const est1 = est0 + (ok1 ? p.nx : 0);
+    T* __restrict__ const est0 = p.dst + (size_t)by * rimg + (size_t)r0 * nx;
+    T* __restrict__ const est1 = est0 + (ok1 ? nx : 0);
     {
-        const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * p.nx : est0;
-        const T* __restrict__ s1 = s0 + (ok1 ? p.nx : 0);
+        const T* __restrict__ s0 = MODE == ROW_RATIO ? p.src + (size_t)by * rimg + (size_t)r0 * nx : est0;
+        const T* __restrict__ s1 = s0 + (ok1 ? nx : 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1085,14 +1098,14 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
     rl_stamp(sync, 1);
     cx<T> v[VMAX];
     cx<T> tl = mk<T>((T)0, (T)0);
-    run_passes<Cfg, true, 0, false>(v, tl, tl_, view_lds, tw, sync);
+    run_passes<Cfg, true, 0, false, (SUBC == 1 && MODE == ROW_UPDATE) ? RL_CT_RESIDUAL : 0>(v, tl, tl_, view_lds, tw, sync);
     rl_stamp(sync, 2);
     // normaliser values (ROW_UPDATE): all of them requested before the first store of the pointwise stage (see
     // rowpass_body), behind the inverse transform (ahead of it they cost NB*R live registers through the transform)
     cx<T> nrm[MODE == ROW_UPDATE ? NB * R : 1];
     if constexpr (MODE == ROW_UPDATE) {
-        const T* __restrict__ n0 = p.norm + (size_t)r0 * p.nx;
-        const T* __restrict__ n1 = n0 + (ok1 ? p.nx : 0);
+        const T* __restrict__ n0 = p.norm + (size_t)r0 * nx;
+        const T* __restrict__ n1 = n0 + (ok1 ? nx : 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1105,9 +1118,9 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
         for (int r = 0; r < R; ++r) {
             const int s = nb * R + r;
             const int i = j + r * NBF;
-            const bool inx = (j < NBF) && (i < p.nx);
+            const bool inx = NXC > 0 ? r * 64 < NXC : (j < NBF) && (i < nx);
             cx<T> z = mk<T>((T)0, (T)0);
-            const bool sub = p.sub_one != 0;
+            const bool sub = SUBC < 0 ? p.sub_one != 0 : SUBC != 0;
             if constexpr (MODE == ROW_RATIO) {
                 z.re = inx ? rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub) : (T)0;
                 z.im = inx && ok1 ? rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub) : (T)0;
@@ -1121,7 +1134,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
         }
     }
     rl_stamp(sync, 3);
-    run_passes<Cfg, false, 0, true>(v, tl, tl_, view_lds, tw, sync);
+    run_passes<Cfg, false, 0, true, (SUBC == 1 && MODE == ROW_RATIO) ? RL_CT_RESIDUAL : 0>(v, tl, tl_, view_lds, tw, sync);
     rl_stamp(sync, 4);
     // natural-order spectrum to LDS, then split it into the two rows' half spectra
     fft_sync<Cfg>(sync);
@@ -1152,7 +1165,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
 // One row pair per wave, Q waves per workgroup, grid (ceil(pairs / Q), images); twiddles from global memory (L1).
 // Replaces rowpass_body for the single-view RL modes of the wave-private lengths: scalar row bases and unconditional
 // loads save ~15 % of its VALU instructions and all of its per-load exec branches.
-template <class Cfg, int Q, int MODE, typename T, class Sync>
+template <class Cfg, int Q, int MODE, typename T, int NXC = 0, int SUBC = -1, class Sync>
 RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* lds, Sync& sync) {
     static_assert(Cfg::T == 64, "lean row body needs wave-private transforms");
     static_assert((size_t)Cfg::L * sizeof(cx<T>) <= RL_STREAM_SLACK, "slack too small");   // overrun < L elements
@@ -1163,7 +1176,7 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     if (r0 >= p.ny) return;   // whole wave; the wave-private row kernels have no workgroup barrier
     RowSpectra<Cfg, T> in;
     in.request(p, by, r0, t, sync);
-    row_item<Cfg, MODE>(p, t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync);
+    row_item<Cfg, MODE, T, NXC, SUBC>(p, t, by, r0, in, LdsView<T, 1, LdsGather<Cfg::L>::value>{lds + q * LP}, p.tw, sync);
 }
 
 
@@ -1181,10 +1194,7 @@ RL_HD void rowlean_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
 // pass leaves: that is what lets FFT -> pointwise -> IFFT chain in the column kernel) and stored from it.
 // Wave-private lengths; an odd frame count leaves the last pair's imaginary part empty.  Multi-view plans: ROW_RATIO runs
 // per (pair, view) image (p.V views), ROW_FWD / ROW_UPDATE on the pair's single (view-summed) spectrum with p.V = 1.
-#ifndef RL_CT_RESIDUAL
-#define RL_CT_RESIDUAL 1      // compact twiddles in the transforms that carry `ratio - 1` (specialised 512-pixel kernels)
-#endif
-// NXC > 0 (round 4): the rows have exactly NXC pixels, a multiple of 64 -- which register slots hold pixels is known at compile
+// NXC > 0 (round 4): the rows have exactly NXC pixels, a multiple of the slot width NBF (64 at L = 576, 256 at L = 2304) -- which register slots hold pixels is known at compile
 // time (no selects, no exec branches around the loads and stores).  SUBC: p.sub_one at compile time (-1: run time).
 // An odd frame count: the last pair's second frame is a PHANTOM COPY of its first (it reads the first frame's images and is
 // never stored), so no value of the pointwise stage depends on whether the partner exists.
@@ -1200,7 +1210,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     static_assert(I0::R == FL::R && I0::NBF == FL::NBF && I0::TAIL == FL::TAIL && I0::NBM == FL::NBM, "spectrum-side layouts must agree");
     static_assert(IL::R == F0::R && IL::NB == F0::NB && !F0::TAIL, "image-side layouts must agree");
     constexpr int R = F0::R, NB = F0::NB, NBF = F0::NBF;
-    static_assert(NXC == 0 || (NXC % 64 == 0 && NXC <= L && TT == 64 && NB == 1 && NBF == 64), "compile-time row length: whole 64-pixel slots");
+    static_assert(NXC == 0 || (NXC % NBF == 0 && NXC <= L && NB == 1), "compile-time row length: whole register slots (NBF pixels each)");
     const int nx = NXC > 0 ? NXC : p.nx;
     const bool sub = SUBC < 0 ? p.sub_one != 0 : SUBC != 0;
     const int q = rl_uniform(tid / TT);
@@ -1218,7 +1228,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     // does register slot s hold a pixel?  (NXC: known at compile time, slot by slot)
     auto in_row = [&](int s) -> bool {
         const int nb = s / R, r = s % R;
-        if constexpr (NXC > 0) return r * 64 < NXC;
+        if constexpr (NXC > 0) return r * NBF < NXC;
         else return (t + nb * TT) < NBF && (t + nb * TT) + r * NBF < nx;
     };
 

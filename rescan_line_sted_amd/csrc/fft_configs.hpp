@@ -40,7 +40,10 @@ struct CfgFor<576> {  // 512 + 53  (the BASELINE headline size)
     // wave-private; radix 9 first so that the row kernels' pointwise stage (inverse's
     // last = forward's first pass) holds elements lane + 64 r: fully coalesced rows
     using Cfg = FftCfg<576, 64, 9, 8, 8>;
-    static constexpr int C32 = 8, C64 = 4, Q32 = 4, Q64 = 4;
+#ifndef RL_576_C32
+#define RL_576_C32 8      // columns (= waves) per column workgroup, f32 (round 4 A/B lever: 16 = whole 128-byte lines, two 16-wave workgroups per CU)
+#endif
+    static constexpr int C32 = RL_576_C32, C64 = 4, Q32 = 4, Q64 = 4;
 };
 template <>
 struct CfgFor<1152> { // 1024 + 53

@@ -65,6 +65,9 @@ constexpr int kC32 = CF::C32, kC64 = CF::C64, kQ32 = CF::Q32, kQ64 = CF::Q64;
 #endif
 template <typename T>
 constexpr bool kColN512 = RL_N512 != 0 && RL_CFG_L == 576 && sizeof(T) == 4;
+// ... and the frame-pair row kernels of L = 2304 for 2048-pixel rows (register slots of 256 pixels: 8 of 9 hold pixels)
+template <typename T>
+constexpr bool kRowN2048 = RL_N512 != 0 && RL_CFG_L == 2304 && sizeof(T) == 4;
 
 
 // NOTE: the transform length is a template parameter of the kernels so that the
@@ -198,7 +201,7 @@ constexpr int row_min_waves() {
     return 1;
 }
 
-template <int L, int Q, int MODE, bool ONEV, typename T, bool PRESUM = false>
+template <int L, int Q, int MODE, bool ONEV, typename T, bool PRESUM = false, int NXC = 0, int SUBC = -1>
 __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, ONEV, T>()))
     k_rowpass(const RowParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -210,8 +213,9 @@ __global__ void __launch_bounds__(CfgFor<L>::Cfg::T* Q, (row_min_waves<L, MODE, 
     // single-view RL modes of the wave-private lengths: the lean item code (scalar row bases,
     // unconditional loads).  RATIO treats every (frame, view) image on its own, so it always qualifies.
     constexpr bool LEAN = !PRESUM && WavePrivate<KCfg>::value && (MODE == ROW_RATIO || (MODE == ROW_UPDATE && ONEV));
+    static_assert(NXC == 0 || LEAN, "the compile-time row length exists for the lean bodies");
     if constexpr (LEAN)
-        rowlean_body<KCfg, Q, MODE, T>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
+        rowlean_body<KCfg, Q, MODE, T, NXC, SUBC>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
     else
         rowpass_body<KCfg, Q, MODE, ONEV, T, PRESUM>(p, (int)threadIdx.x, (int)bx, (int)by, reinterpret_cast<cx<T>*>(smem), s);
 }
@@ -295,6 +299,14 @@ static hipError_t launch_row_pair_t(int mode, const void* params, unsigned gy, h
                 return hipGetLastError();
             }
         }
+        if constexpr (kRowN2048<T>) {
+            if (p.nx == 2048 && p.V == 1 && p.sub_one != 0 && mode != ROW_FWD) {
+                if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T, 2048, 1>, grid, block, lds, s, p);
+                else if (mode == ROW_UPDATE) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T, 2048, 1>, grid, block, lds, s, p);
+                else return hipErrorInvalidValue;
+                return hipGetLastError();
+            }
+        }
         if (mode == ROW_FWD) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_FWD, T>, grid, block, lds, s, p);
         else if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T>, grid, block, lds, s, p);
         else if (mode == ROW_UPDATE) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_UPDATE, T>, grid, block, lds, s, p);
@@ -312,6 +324,12 @@ static hipError_t launch_row_m(const void* params, unsigned gx, unsigned gy, hip
     if constexpr (MODE == ROW_UPDATE) {
         if (p.V > 1 && p.sub_one) {   // the views' residual spectra are summed on their way in: one inverse transform (rowpass_body PRESUM)
             rl_launch(k_rowpass<RL_CFG_L, Q, MODE, true, T, true>, dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s, p);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (kColN512<T> && (MODE == ROW_RATIO || MODE == ROW_UPDATE)) {   // per-frame lean bodies on 512-pixel rows (multi-view plans' RATIO,
+        if (p.nx == 512 && p.sub_one != 0 && (MODE == ROW_RATIO || p.V == 1)) {   // the single-spectrum UPDATE behind the column view sum, f32)
+            rl_launch(k_rowpass<RL_CFG_L, Q, MODE, MODE == ROW_UPDATE, T, false, 512, 1>, dim3(gx, gy), dim3(Cfg::T * Q), lds_bytes<Q, T>(), s, p);
             return hipGetLastError();
         }
     }
@@ -409,6 +427,10 @@ static hipError_t prepare_rows() {
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, true, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, false, T>, b)) != hipSuccess) return e;
     if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_ADJ, true, T>, b)) != hipSuccess) return e;
+    if constexpr (kColN512<T>) {
+        if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_RATIO, false, T, false, 512, 1>, b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rowpass<RL_CFG_L, Q, ROW_UPDATE, true, T, false, 512, 1>, b)) != hipSuccess) return e;
+    }
     if constexpr (kPairRows) {
         constexpr int QP = sizeof(T) == 4 ? kPairQ32 : Q;
         const size_t bp = lds_bytes<QP, T>();
@@ -418,6 +440,10 @@ static hipError_t prepare_rows() {
         if constexpr (kColN512<T>) {
             if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_RATIO, T, 512, 1>, bp)) != hipSuccess) return e;
             if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_UPDATE, T, 512, 1>, bp)) != hipSuccess) return e;
+        }
+        if constexpr (kRowN2048<T>) {
+            if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_RATIO, T, 2048, 1>, bp)) != hipSuccess) return e;
+            if ((e = allow_lds(k_rowpair<RL_CFG_L, QP, ROW_UPDATE, T, 2048, 1>, bp)) != hipSuccess) return e;
         }
     }
     return hipSuccess;

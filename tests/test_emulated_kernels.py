@@ -546,3 +546,34 @@ def test_compile_time_size_bodies(emu):
         pad[:n] = sin[b_, :, :pl.kx]
         ref = np.fft.ifft(np.fft.fft(pad, axis=0) * pl.psf_hat_natural[0, :, :pl.kx], axis=0)[:n] * L
         assert max_rel(outs[1][b_], ref) < 1e-13
+
+
+@pytest.mark.parametrize('M,real_psf', [(4, 1), (2, 0), (8, 1)])
+def test_outer_body_with_the_row_count_at_compile_time(emu, M, real_psf):
+    """colconv_outer_body<..., NYC> (the device: images of M x 512 rows on the 576 core; here M x 192 rows on the 256 core): every
+    residue class has whole 64-row steps, the rows of a class's tile that do not exist are constants, pad columns travel with the
+    tile -- bit for bit the generic body's result, and numpy's."""
+    emu.emu_set_special.argtypes = [ctypes.c_int]
+    Li, ny, kx, V, frames = 256, M * 192, 11, 1, 2
+    L, pitch = M * Li, 16
+    rng = np.random.default_rng(900 + M)
+    x = np.zeros((frames, ny, pitch), dtype=np.complex128)
+    x[:, :, :kx] = rng.standard_normal((frames, ny, kx)) + 1j * rng.standard_normal((frames, ny, kx))
+    ph = rng.standard_normal((V, kx, L)) + (0 if real_psf else 1j) * rng.standard_normal((V, kx, L))
+    psf_arg = np.ascontiguousarray(ph.real if real_psf else ph.astype(np.complex128))
+    outs = []
+    for special in (0, 1):
+        out = np.zeros((frames * V, ny, pitch), dtype=np.complex128)
+        emu.emu_set_special(special)
+        try:
+            assert emu.emu_col_outer_f64(Li, M, _p(_slack(x)), _p(out), _p(psf_arg), real_psf, ny, kx, pitch, V, frames, 1, 0) == 0
+        finally:
+            emu.emu_set_special(0)
+        outs.append(out[:, :, :kx].copy())
+    assert np.array_equal(outs[0], outs[1])
+    full = np.zeros((frames, L, kx), dtype=np.complex128)
+    full[:, :ny] = x[:, :, :kx]
+    spec = np.fft.fft(full, axis=1)
+    for f in range(frames):
+        ref = np.fft.ifft(spec[f] * ph[0].T, axis=0)[:ny] * L
+        assert max_rel(outs[1][f], ref) < 1e-12
