@@ -184,6 +184,9 @@ int rl_batch_submit(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters
 int rl_device_alloc(rl_ctx* ctx, size_t bytes, void** dev_out);
 int rl_device_free(rl_ctx* ctx, void* dev);
 int rl_device_download(rl_ctx* ctx, const void* dev, int dtype, size_t n_elements, double* host_out);
+/* host float64 -> n elements of `dtype` at a device address of this GPU (a caller's buffer, or a plan buffer handed out by
+ * rl_deconv_device_ptr -- the zero-copy way to replace a measurement: the plan re-measures its frames' levels before the next run). */
+int rl_device_upload(rl_ctx* ctx, void* dev, int dtype, size_t n_elements, const double* host);
 
 /* ---- multi-GPU: one process per GPU, frames sharded over ranks -----------------
  * The reference is single process; independent simulations shard with no

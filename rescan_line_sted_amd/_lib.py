@@ -57,6 +57,7 @@ PROTOTYPES = {
     'rl_device_alloc': (_i, [_vp, _c.c_size_t, _c.POINTER(_vp)]),
     'rl_device_free': (_i, [_vp, _vp]),
     'rl_device_download': (_i, [_vp, _vp, _i, _c.c_size_t, _dp]),
+    'rl_device_upload': (_i, [_vp, _vp, _i, _c.c_size_t, _dp]),
     'rl_comm_gather_device': (_i, [_vp, _vp, _c.POINTER(_c.c_size_t), _i, _i, _vp]),
     'rl_comm_bcast_host': (_i, [_vp, _dp, _c.c_size_t, _i]),
     'rl_comm_unique_id': (_i, [_vp]),

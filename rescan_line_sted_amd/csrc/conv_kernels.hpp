@@ -22,6 +22,9 @@
 #pragma once
 #include "fft_core.hpp"
 
+#ifndef RL_TILE_WIDE
+#define RL_TILE_WIDE 1        // 16-byte accesses in the column tile I/O of the compile-time-size kernels (colconv_wave_body WIDE)
+#endif
 #ifndef RL_CT_RESIDUAL
 #define RL_CT_RESIDUAL 1      // compact twiddles in the transforms that carry `ratio - 1` (kernels with `sub_one` at compile time)
 #endif
@@ -245,7 +248,32 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     const bool cok = NYC > 0 ? true : (int)(col0 + c_) < p.kx;
     const unsigned boff = (r_lo * (unsigned)p.pitch + (unsigned)col0 + c_) * (unsigned)sizeof(cx<T>);
     const size_t step = (size_t)64 * p.pitch * sizeof(cx<T>);
+    // WIDE (round 4; the compile-time-size kernels): a thread moves TWO neighbouring columns of a row with one 16-byte access (f64:
+    // two) -- thread -> (row tid / (C/2) + 128 it, columns 2 (tid % (C/2)), + 1) -- half the vector-memory instructions of the
+    // tile load and store for the same bytes (16 bytes per lane is the width the memory pipeline is built for).
+    constexpr bool WIDE = RL_TILE_WIDE != 0 && NYC > 0 && NYC % 128 == 0 && C % 2 == 0;
+    struct alignas(2 * sizeof(cx<T>)) cx2 {
+        cx<T> a, b;
+    };
+    const unsigned w_cp = (unsigned)tid % (C / 2), w_r = (unsigned)tid / (C / 2);      // (64 C threads: 128 rows per step)
+    const unsigned w_off = (w_r * (unsigned)p.pitch + (unsigned)col0 + 2 * w_cp) * (unsigned)sizeof(cx<T>);
+    const size_t w_step = (size_t)128 * p.pitch * sizeof(cx<T>);
     auto load_tile = [&](const cx<T>* __restrict__ in) {
+        if constexpr (WIDE) {
+            constexpr int NW = NYC / 128;
+            cx2 y[NW];
+#pragma unroll
+            for (int it = 0; it < NW; ++it) y[it] = *reinterpret_cast<const cx2*>(reinterpret_cast<const char*>(in) + it * w_step + w_off);
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                lds[(2 * w_cp) * LP + view_lds.nat(w_r + 128 * it)] = y[it].a;
+                lds[(2 * w_cp + 1) * LP + view_lds.nat(w_r + 128 * it)] = y[it].b;
+            }
+            // rows NYC .. L - 1 of the tile are zero
+#pragma unroll
+            for (int e = tid; e < (L - NYC) * C; e += NT) lds[(e % C) * LP + view_lds.nat(NYC + e / C)] = mk<T>((T)0, (T)0);
+            return;
+        }
         cx<T> x[NLD];   // all global loads are issued before the first LDS write
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -257,6 +285,16 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
         for (int it = 0; it < NLD; ++it) lds[c_ * LP + view_lds.nat(r_lo + 64 * it)] = x[it];
     };
     auto store_tile = [&](cx<T>* __restrict__ out) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int it = 0; it < NYC / 128; ++it) {
+                cx2 y;
+                y.a = rl_spec_round(lds[(2 * w_cp) * LP + view_lds.nat(w_r + 128 * it)], p.qscale);
+                y.b = rl_spec_round(lds[(2 * w_cp + 1) * LP + view_lds.nat(w_r + 128 * it)], p.qscale);
+                *reinterpret_cast<cx2*>(reinterpret_cast<char*>(out) + it * w_step + w_off) = y;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             char* sb = reinterpret_cast<char*>(out) + it * step;
@@ -454,7 +492,25 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     const unsigned boff = ((unsigned)M * r_lo * (unsigned)p.pitch + (unsigned)col0 + c_) * (unsigned)sizeof(cx<T>);
     const size_t row_bytes = (size_t)p.pitch * sizeof(cx<T>);
     auto row_ok = [&](int q, int it) -> bool { return (int)(M * (r_lo + 64 * it)) + q < ny; };   // (NYC: it < NYC / (64 M), whatever q)
+    // WIDE (as colconv_wave_body's): two neighbouring columns of a row per 16-byte access -- thread -> (class row tid / (C/2) + 128 it,
+    // columns 2 (tid % (C/2)), + 1); x[2 it], x[2 it + 1] hold the pair
+    constexpr int NYQ = NYC / M;                                    // rows of a residue class
+    constexpr bool WIDE = RL_TILE_WIDE != 0 && NYC > 0 && NYQ % 128 == 0 && C % 2 == 0 && 2 * (NYQ / 128) <= NLD;
+    struct alignas(2 * sizeof(cx<T>)) cx2 {
+        cx<T> a, b;
+    };
+    const unsigned w_cp = (unsigned)tid % (C / 2), w_r = (unsigned)tid / (C / 2);
+    const unsigned w_off = ((unsigned)M * w_r * (unsigned)p.pitch + (unsigned)col0 + 2 * w_cp) * (unsigned)sizeof(cx<T>);
     auto fetch_class = [&](const cx<T>* __restrict__ in, int q, cx<T> (&x)[NLD]) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int it = 0; it < NYQ / 128; ++it) {
+                const cx2 y = *reinterpret_cast<const cx2*>(reinterpret_cast<const char*>(in) + ((size_t)M * 128 * it + q) * row_bytes + w_off);
+                x[2 * it] = y.a;
+                x[2 * it + 1] = y.b;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const char* sb = reinterpret_cast<const char*>(in) + ((size_t)M * 64 * it + q) * row_bytes;
@@ -463,6 +519,16 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
         }
     };
     auto park_class = [&](const cx<T> (&x)[NLD]) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int it = 0; it < NYQ / 128; ++it) {
+                lds[(2 * w_cp) * LP + view_lds.nat(w_r + 128 * it)] = x[2 * it];
+                lds[(2 * w_cp + 1) * LP + view_lds.nat(w_r + 128 * it)] = x[2 * it + 1];
+            }
+#pragma unroll
+            for (int e = tid; e < (Li - NYQ) * C; e += NT) lds[(e % C) * LP + view_lds.nat(NYQ + e / C)] = mk<T>((T)0, (T)0);   // rows NYQ .. Li - 1 are zero
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) lds[c_ * LP + view_lds.nat(r_lo + 64 * it)] = x[it];
     };
@@ -472,6 +538,16 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
         park_class(x);
     };
     auto store_class = [&](cx<T>* __restrict__ out, int q) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int it = 0; it < NYQ / 128; ++it) {
+                cx2 y;
+                y.a = rl_spec_round(lds[(2 * w_cp) * LP + view_lds.nat(w_r + 128 * it)], p.qscale);
+                y.b = rl_spec_round(lds[(2 * w_cp + 1) * LP + view_lds.nat(w_r + 128 * it)], p.qscale);
+                *reinterpret_cast<cx2*>(reinterpret_cast<char*>(out) + ((size_t)M * 128 * it + q) * row_bytes + w_off) = y;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             char* sb = reinterpret_cast<char*>(out) + ((size_t)M * 64 * it + q) * row_bytes;

@@ -1669,6 +1669,27 @@ int rl_device_free(rl_ctx* ctx, void* dev) {
     return RL_OK;
 }
 
+int rl_device_upload(rl_ctx* ctx, void* dev, int dtype, size_t n_elements, const double* host) {
+    if (!ctx || (n_elements && (!dev || !host))) return fail(RL_ERR_INVALID, "NULL argument");
+    if (dtype != RL_F32 && dtype != RL_F64) return fail(RL_ERR_INVALID, "dtype must be RL_F32 or RL_F64");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (dtype == RL_F64) {
+        HIP_TRY(hipMemcpyAsync(dev, host, n_elements * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return RL_OK;
+    }
+    const size_t piece = std::min(n_elements, (size_t)16 << 20);
+    double* w = nullptr;
+    RL_TRY(ctx->psf_workspace(piece, &w));
+    for (size_t o = 0; o < n_elements; o += piece) {
+        const size_t m = std::min(piece, n_elements - o);
+        HIP_TRY(hipMemcpyAsync(w, host + o, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(aux_cast(RL_F64, w, RL_F32, (char*)dev + o * 4, m, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return RL_OK;
+}
+
 int rl_device_download(rl_ctx* ctx, const void* dev, int dtype, size_t n_elements, double* host_out) {
     if (!ctx || (n_elements && (!dev || !host_out))) return fail(RL_ERR_INVALID, "NULL argument");
     if (dtype != RL_F32 && dtype != RL_F64) return fail(RL_ERR_INVALID, "dtype must be RL_F32 or RL_F64");

@@ -116,6 +116,10 @@ static int col_t(const T* in, T* out, const T* psf_hat, int ny, int kx, int pitc
                          colconv_wave_body<Cfg, C, COL_PER_IMAGE, T, false, 192, 1>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
                          return;
                      }
+                     if (g_special && ny == 128 && V == 1 && mode == COL_PER_IMAGE && pitch % C == 0) {   // (a multiple of 128 rows: the 16-byte tile I/O)
+                         colconv_wave_body<Cfg, C, COL_PER_IMAGE, T, false, 128, 1>(p, tid, bx, by, reinterpret_cast<cx<T>*>(lds), s);
+                         return;
+                     }
                  }
                  if constexpr (WavePrivate<Cfg>::value)
                      switch (mode) {   // same dispatch as launch_col_t in fft_kernels.hip
@@ -274,6 +278,11 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
                      if (g_special && ny == M * 192 && pitch % C == 0) {
                          if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_PER_IMAGE, 0, 0, M * 192>(p, tid, bx, by, l, s);
                          else colconv_outer_body<Core, M, C, T, false, COL_PER_IMAGE, 0, 0, M * 192>(p, tid, bx, by, l, s);
+                         return;
+                     }
+                     if (g_special && ny == M * 128 && pitch % C == 0) {   // (classes of 128 rows: the 16-byte tile I/O)
+                         if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_PER_IMAGE, 0, 0, M * 128>(p, tid, bx, by, l, s);
+                         else colconv_outer_body<Core, M, C, T, false, COL_PER_IMAGE, 0, 0, M * 128>(p, tid, bx, by, l, s);
                          return;
                      }
                  }

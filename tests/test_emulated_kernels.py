@@ -527,7 +527,13 @@ def test_compile_time_size_bodies(emu):
     a, b = run_rows(0), run_rows(1)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
-    # column pass: 192 rows of 256, one view, 19 spectrum columns (pitch 24: pad columns beside the last tile's valid ones)
+    # column pass: 192 rows of 256 (and 128: the two-columns-per-access tile I/O), one view, 33 spectrum columns (pitch 40: pad
+    # columns beside the last tile's valid ones)
+    for n in (192, 128):
+        _check_special_column_pass(emu, rng, L, n)
+
+
+def _check_special_column_pass(emu, rng, L, n):
     pl = EmuPlan(emu, [rng.random((1, 5, 3))], n, 36, L, 64)
     sin = pl.spec(2)
     sin[:, :, :pl.kx] = rng.random((2, n, pl.kx)) + 1j * rng.random((2, n, pl.kx))
@@ -548,13 +554,13 @@ def test_compile_time_size_bodies(emu):
         assert max_rel(outs[1][b_], ref) < 1e-13
 
 
-@pytest.mark.parametrize('M,real_psf', [(4, 1), (2, 0), (8, 1)])
-def test_outer_body_with_the_row_count_at_compile_time(emu, M, real_psf):
+@pytest.mark.parametrize('M,real_psf,rows', [(4, 1, 192), (2, 0, 192), (8, 1, 192), (4, 0, 128), (2, 1, 128)])
+def test_outer_body_with_the_row_count_at_compile_time(emu, M, real_psf, rows):
     """colconv_outer_body<..., NYC> (the device: images of M x 512 rows on the 576 core; here M x 192 rows on the 256 core): every
     residue class has whole 64-row steps, the rows of a class's tile that do not exist are constants, pad columns travel with the
     tile -- bit for bit the generic body's result, and numpy's."""
     emu.emu_set_special.argtypes = [ctypes.c_int]
-    Li, ny, kx, V, frames = 256, M * 192, 11, 1, 2
+    Li, ny, kx, V, frames = 256, M * rows, 11, 1, 2      # (rows = 128: whole 128-row steps -- the two-columns-per-access tile I/O)
     L, pitch = M * Li, 16
     rng = np.random.default_rng(900 + M)
     x = np.zeros((frames, ny, pitch), dtype=np.complex128)

@@ -227,24 +227,28 @@ def test_measurement_written_through_the_device_pointer_is_not_paired_blindly(li
     """rl_deconv_device_ptr(which = 1) hands out the measurement buffer (the zero-copy drop-in path); what the host
     knew about the frames' levels is void from then on, so the next run recomputes the per-frame sums on the device before it
     chooses between the pair loop and the per-frame loop."""
-    torch = pytest.importorskip('torch')
+    import ctypes
     psf = list(golden('g8_fig2_psfs')['2p0x_lr/point_sted_psf'])
     plan = lib.DeconvPlan(psf, 4, 512, 512, dtype='f32')
     plan.set_object(np.stack([astronaut512] * 4), 8e11)
     plan.simulate(seed=5)
     assert plan.strategy()['frame_pairs']
-    m = torch.as_tensor(plan.device_array('measurement'), device='cuda')
-    m[1] *= 1e-4                                          # frame 1 now 1e4 times dimmer than its partner
-    torch.cuda.synchronize()
+    noisy = plan.measurement()
+
+    def write_frame_1(values):      # straight into the plan's buffer (rl_device_upload at the address rl_deconv_device_ptr hands out)
+        arr = plan.device_array('measurement')
+        addr = arr.__cuda_array_interface__['data'][0] + 512 * 512 * 4      # frame 1 of the f32 buffer
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        lib.check(lib.lib.rl_device_upload(plan.ctx.handle, ctypes.c_void_p(addr), lib.RL_F32, v.size, lib.ptr(v)))
+    write_frame_1(noisy[1, 0] * 1e-4)                     # frame 1 now 1e4 times dimmer than its partner
     plan.reset_estimate()
     plan.iterate(2)
     assert not plan.strategy()['frame_pairs']             # the per-frame loop ran
-    m[1] *= 1e4
-    torch.cuda.synchronize()
-    plan.device_array('measurement')                      # (handing it out again: the levels are looked at again)
+    write_frame_1(noisy[1, 0])
     plan.reset_estimate()
     plan.iterate(2)
     assert plan.strategy()['frame_pairs']
+    assert np.array_equal(plan.measurement(), noisy.astype(np.float32).astype(np.float64))
 
 
 def test_multi_view_measurement_with_negative_pixels_keeps_the_per_view_clamp(lib, golden, monkeypatch):
