@@ -319,6 +319,27 @@ hipError_t aux_image_sums(int dtype, const void* src, size_t n, size_t frames, d
     return hipGetLastError();
 }
 
+// dst[f][i] = (T)(src[idx[f]][i] * (target[f] / sums[idx[f]]))   (target == nullptr: plain conversion): frames that share an
+// object (a sweep's seeds) are staged and uploaded once
+template <typename T>
+__global__ void k_scale_convert_indexed(const double* __restrict__ src, const unsigned* __restrict__ idx, T* __restrict__ dst, size_t n,
+                                        size_t frames, const double* __restrict__ target, const double* __restrict__ sums) {
+    const size_t total = n * frames;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n, u = idx[f];
+        const double k = target ? target[f] / sums[u] : 1.0;
+        dst[i] = (T)(src[u * n + (i - f * n)] * k);
+    }
+}
+hipError_t aux_scale_convert_indexed(int dtype, const double* src, const unsigned* idx, size_t n_unique, void* dst, size_t n, size_t frames,
+                                     const double* target, double* sums, hipStream_t s) {
+    if (target) k_frame_sums<double><<<(unsigned)n_unique, 1024, 0, s>>>(src, n, sums);
+    const unsigned g = blocks_for(n * frames, 256);
+    if (dtype == DT_F32) k_scale_convert_indexed<float><<<g, 256, 0, s>>>(src, idx, (float*)dst, n, frames, target, sums);
+    else k_scale_convert_indexed<double><<<g, 256, 0, s>>>(src, idx, (double*)dst, n, frames, target, sums);
+    return hipGetLastError();
+}
+
 hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s) {
     const unsigned g = blocks_for(total, 256);
     if (dtype == DT_F32) k_to_f64<float><<<g, 256, 0, s>>>((const float*)src, dst, total);

@@ -29,6 +29,9 @@ hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, 
 hipError_t aux_any_negative(int dtype, const void* src, size_t n, int* flag, hipStream_t s);
 // sums[f] = sum of image f of a stack [frames][n] in the plan's dtype (float64 accumulation)
 hipError_t aux_image_sums(int dtype, const void* src, size_t n, size_t frames, double* sums, hipStream_t s);
+// as aux_scale_convert with frame f taken from staged object idx[f] (n_unique staged objects; sums: [n_unique] scratch)
+hipError_t aux_scale_convert_indexed(int dtype, const double* src, const unsigned* idx, size_t n_unique, void* dst, size_t n, size_t frames,
+                                     const double* target, double* sums, hipStream_t s);
 hipError_t aux_to_f64(int dtype, const void* src, double* dst, size_t total, hipStream_t s);
 // dst[i] = (dst type) src[i]: a plan buffer into a result buffer of another arithmetic type (same type: a device copy)
 hipError_t aux_cast(int dtype_src, const void* src, int dtype_dst, void* dst, size_t total, hipStream_t s);

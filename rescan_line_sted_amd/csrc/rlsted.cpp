@@ -120,8 +120,10 @@ struct rl_deconv {
     size_t slice_ws_bytes = 0, slice_ws_stride = 0;
     // ---- rl_batch_submit: the tasks of a chunk -- objects, brightness targets, Philox keys -- are staged in one page-locked
     // block, uploaded on a copy stream of the plan's own and consumed on the context's stream; two blocks, so that chunk i + 1
-    // is staged and uploaded while chunk i iterates.  Block layout (host and device): [B][n_img] float64 objects, [B] float64
-    // targets, [B] uint64 seeds, [B] uint32 image ids; the device block is followed by [B] float64 sums.
+    // is staged and uploaded while chunk i iterates.  Block layout (host and device): header -- [B] float64 targets, [B] uint64
+    // seeds, [B] uint32 image ids, [B] uint32 object index -- then the chunk's DISTINCT objects, [<= B][n_img] float64 (tasks that
+    // share an object pointer -- a sweep's seeds -- are staged and uploaded once; only the used prefix of the block crosses PCIe);
+    // the device block is followed by [B] float64 sums.
     struct BatchSlot {
         char* host = nullptr;
         char* dev = nullptr;
@@ -136,7 +138,8 @@ struct rl_deconv {
     const unsigned long long* run_key_seeds = nullptr;   // keyed Poisson draws of run_slices (device, [B]); nullptr: one seed
     const unsigned* run_key_ids = nullptr;
     size_t slot_objects_bytes() const { return (size_t)B * n_img() * sizeof(double); }
-    size_t slot_host_bytes() const { return slot_objects_bytes() + (size_t)B * (8 + 8 + 4); }
+    size_t slot_header_bytes() const { return ((size_t)B * (8 + 8 + 4 + 4) + 15) / 16 * 16; }
+    size_t slot_host_bytes() const { return slot_header_bytes() + slot_objects_bytes(); }
     int ensure_batch_slots() {
         if (copy_stream) return RL_OK;
         HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
@@ -410,6 +413,7 @@ struct rl_deconv {
     // The split column pass (conv_kernels.hpp COL_SPLIT_*; f32 multi-view plans on the long column transforms): H transforms a frame's
     // spectrum once for its V views, H_t sums the views' products before one inverse transform (RLSTED_COL_SPLIT=0: A/B knob)
     bool split_wanted = true;
+    bool split_ht = true;    // H_t through the split pass (RLSTED_SPLIT_HT=0: V whole-pass launches + the pre-summed update; measured)
     bool split_h = true;     // H through the split pass too (RLSTED_SPLIT_H=0: H_t only -- measured in round 4)
     bool col_split() const { return split_wanted && dtype == RL_F32 && V > 1 && ty->split_tile_elems > 0; }
     size_t n_spec_x() const { return (size_t)((kx + ty->C[RL_F32] - 1) / ty->C[RL_F32]) * ty->split_tile_elems; }
@@ -746,7 +750,7 @@ struct rl_deconv {
                 else RL_TRY(col(sa, sb, nf, true));          // (RLSTED_SPLIT_H=0: V whole-pass launches, nothing parked on this side)
                 RL_TRY(row(ROW_RATIO, (unsigned)(nf * V), sb, sb, off(meas, (size_t)f0 * V * n_img()), nullptr, nullptr));
             }
-            if (fuse_views) {
+            if (fuse_views && split_ht) {
                 RL_TRY(col_split_pass(sb, sa, sx, nf, COL_HT_FUSED));
                 RL_TRY(row(ROW_UPDATE, (unsigned)nf, sa, sa, nullptr, off(est, (size_t)f0 * n_img()), norm, nullptr, 1));
             } else {
@@ -1293,6 +1297,7 @@ int rl_deconv_create(rl_ctx* ctx, const double* psfs, int n_psf, int py, int px,
         if (h->lanes > rl_deconv::kMaxLanes) h->lanes = rl_deconv::kMaxLanes;
     }
     if (getenv("RLSTED_COL_SPLIT")) h->split_wanted = atoi(getenv("RLSTED_COL_SPLIT")) != 0;
+    if (getenv("RLSTED_SPLIT_HT")) h->split_ht = atoi(getenv("RLSTED_SPLIT_HT")) != 0;
     // H through the split pass from three views on: with two the forward half saved (1 + V against 2 V column transforms) does not pay
     // for parking the spectrum -- measured, 2048^2: 2 views 429 (split) against 449 frames/s, 4 views 269 against 258
     h->split_h = getenv("RLSTED_SPLIT_H") ? atoi(getenv("RLSTED_SPLIT_H")) != 0 : n_psf >= 3;
@@ -1579,15 +1584,23 @@ int rl_batch_submit(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters
         const int nt = std::min(B, n_tasks - t0);
         rl_deconv::BatchSlot& sl = h->bslot[h->batch_chunks++ % 2];
         if (sl.used) HIP_TRY(hipEventSynchronize(sl.freed));   // the chunk before last has consumed this block
-        double* objs = (double*)sl.host;
-        double* tb = (double*)(sl.host + h->slot_objects_bytes());
+        double* tb = (double*)sl.host;
         uint64_t* seeds = (uint64_t*)(tb + B);
         uint32_t* ids = (uint32_t*)(seeds + B);
+        uint32_t* idx = ids + B;
+        double* objs = (double*)(sl.host + h->slot_header_bytes());
         bool scaled = true;
         std::vector<double> level((size_t)B, 0.0);
+        std::vector<const double*> uniq;
         for (int f = 0; f < B; ++f) {   // a short last chunk repeats its last task (the plan's batch is fixed)
             const rl_task& t = tasks[t0 + std::min(f, nt - 1)];
-            memcpy(objs + (size_t)f * n, t.object, n * sizeof(double));
+            size_t u = 0;
+            while (u < uniq.size() && uniq[u] != t.object) ++u;     // (a handful of distinct objects per chunk)
+            if (u == uniq.size()) {
+                uniq.push_back(t.object);
+                memcpy(objs + u * n, t.object, n * sizeof(double));
+            }
+            idx[f] = (uint32_t)u;
             tb[f] = t.total_brightness;
             scaled = scaled && t.total_brightness > 0;
             seeds[f] = t.seed;
@@ -1595,25 +1608,26 @@ int rl_batch_submit(rl_deconv* h, const rl_task* tasks, int n_tasks, int k_iters
         }
         // the frames' levels (what pairs frames of comparable brightness, rl_deconv::choose_loop) are known on the host: the
         // targets, or -- unscaled objects -- their sums
-        for (int f = 0; f < B; ++f) {
-            if (scaled) {
-                level[f] = tb[f];
-            } else {
-                double t = 0.0;
-                for (size_t i = 0; i < n; ++i) t += objs[(size_t)f * n + i];
-                level[f] = t;
-            }
+        if (scaled) {
+            for (int f = 0; f < B; ++f) level[f] = tb[f];
+        } else {
+            std::vector<double> usum(uniq.size(), 0.0);
+            for (size_t u = 0; u < uniq.size(); ++u)
+                for (size_t i = 0; i < n; ++i) usum[u] += objs[u * n + i];
+            for (int f = 0; f < B; ++f) level[f] = usum[idx[f]];
         }
-        HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, h->slot_host_bytes(), hipMemcpyHostToDevice, h->copy_stream));
+        const size_t used = h->slot_header_bytes() + uniq.size() * n * sizeof(double);
+        HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, used, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipEventRecord(sl.uploaded, h->copy_stream));
         HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
-        const double* d_objs = (const double*)sl.dev;
-        const double* d_tb = (const double*)(sl.dev + h->slot_objects_bytes());
+        const double* d_tb = (const double*)sl.dev;
         const unsigned long long* d_seeds = (const unsigned long long*)(d_tb + B);
         const unsigned* d_ids = (const unsigned*)(d_seeds + B);
+        const unsigned* d_idx = d_ids + B;
+        const double* d_objs = (const double*)(sl.dev + h->slot_header_bytes());
         double* d_sums = (double*)(sl.dev + (h->slot_host_bytes() + 7) / 8 * 8);
         // :505-506  obj *= total_brightness / obj.sum(), per frame, on the device
-        HIP_TRY(aux_scale_convert(h->dtype, d_objs, h->obj, n, (size_t)B, scaled ? d_tb : nullptr, d_sums, s, scaled));
+        HIP_TRY(aux_scale_convert_indexed(h->dtype, d_objs, d_idx, uniq.size(), h->obj, n, (size_t)B, scaled ? d_tb : nullptr, d_sums, s));
         h->obj_level = level;
         h->meas_level = level;
         h->choose_loop(h->meas_level);

@@ -53,11 +53,30 @@ PLAN_CACHE_MAX = 128
 _plans = {}
 
 
+_set_keys = {}      # id(list of PSF arrays) -> (the list, its arrays, per-array (sum, sum of squares), (digest, stack))
+
+
+def _psf_set_key(psfs):
+    """(sha1 of the PSF stack, the stack).  Hashing 18 sets of up to ten 107 x 107 float64 PSFs is milliseconds per sweep -- as much
+    as the device needs for a quarter of it -- so a set that is the SAME list of the SAME arrays as last time, with unchanged sums and
+    sums of squares (an in-place edit shows there), is not hashed again."""
+    ent = _set_keys.get(id(psfs))
+    probe = tuple((float(np.sum(p)), float(np.square(p).sum())) for p in psfs)     # (no BLAS call: its thread pool costs more than the sums)
+    if ent is not None and ent[0] is psfs and len(ent[1]) == len(psfs) and all(a is b for a, b in zip(ent[1], psfs)) and ent[2] == probe:
+        return ent[3]
+    stack = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).reshape((1,) + np.shape(p)[-2:]) for p in psfs]))
+    val = (hashlib.sha1(stack.tobytes()).hexdigest(), stack)
+    if len(_set_keys) > 4 * PLAN_CACHE_MAX:
+        _set_keys.clear()
+    _set_keys[id(psfs)] = (psfs, list(psfs), probe, val)
+    return val
+
+
 def plan_for(psfs, batch, shape, dtype='f32', device=0, stream=0):
     """The plan of a (PSF set, image shape, batch): built on first use, kept for the next sweep (the reference builds its
     Deconvolvers once per figure too, line_sted_figure_2.py:39-45).  `stream`: which of the device's contexts it lives on."""
-    stack = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).reshape((1,) + np.shape(p)[-2:]) for p in psfs]))
-    key = (hashlib.sha1(stack.tobytes()).hexdigest(), stack.shape, int(batch), tuple(shape), dtype, device, stream)
+    digest, stack = _psf_set_key(psfs)
+    key = (digest, stack.shape, int(batch), tuple(shape), dtype, device, stream)
     plan = _plans.pop(key, None)
     if plan is None:
         plan = DeconvPlan([p[None] for p in stack], batch, shape[0], shape[1], dtype=dtype, device=device, stream=stream)
@@ -69,6 +88,7 @@ def plan_for(psfs, batch, shape, dtype='f32', device=0, stream=0):
 
 def clear_plans():
     _plans.clear()
+    _set_keys.clear()
 
 
 class DeviceResults:
@@ -111,12 +131,16 @@ def split_flat(flat, shapes):
     return out
 
 
-SWEEP_STREAMS = 3      # contexts of one GPU the groups of a sweep are dealt to in turn (their launches overlap)
+SWEEP_STREAMS = 4      # contexts of one GPU the groups of a sweep are dealt to in turn (their launches overlap); measured on
+#                        config 4's 1152 tasks: 1 / 2 / 3 / 4 / 6 / 8 contexts 43.7 / 34.0 / 31.6 / 30.7 / 31.4 / 33.3 ms
 
 
 def run_tasks_device(tasks, objects, psf_sets, iterations, total_brightness=5e10, dtype='f32', device=0,
-                     max_frames_per_plan=256, streams=SWEEP_STREAMS):
-    """Enqueue the tasks on one GPU (group by group, `rl_batch_submit`), synchronise once; returns their DeviceResults."""
+                     max_frames_per_plan=256, streams=SWEEP_STREAMS, timing=None):
+    """Enqueue the tasks on one GPU (group by group, `rl_batch_submit`), synchronise once; returns their DeviceResults.
+    timing (dict, optional): receives 'enqueue_s', the host's share (staging + launches) before the one synchronisation."""
+    import time
+    t_start = time.perf_counter()
     ids = object_ids(objects)
     res = DeviceResults([objects[o].shape[-2:] for o, _, _ in tasks], dtype, device)
     groups = {}
@@ -138,6 +162,8 @@ def run_tasks_device(tasks, objects, psf_sets, iterations, total_brightness=5e10
             for a, b in runs:                         # maximal runs of tasks that are neighbours in the result buffer
                 plan.batch_submit(frames[a:b], total_brightness, [tasks[i][2] for i in part[a:b]], [ids[tasks[i][0]] for i in part[a:b]],
                                   iterations, res.address(part[a]), dtype, rng=RNG_PHILOX)
+    if timing is not None:
+        timing['enqueue_s'] = time.perf_counter() - t_start
     for st in used:
         Context.get(device, st).synchronize()
     return res
