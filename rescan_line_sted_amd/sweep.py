@@ -116,7 +116,7 @@ class DeviceResults:
         return split_flat(flat, self.shapes)
 
     def free(self):
-        if getattr(self, 'dev', None) is not None and self.dev.value:
+        if getattr(self, 'dev', None) is not None and self.dev.value and lib is not None:    # (lib: gone at interpreter shutdown)
             lib.rl_device_free(self.ctx.handle, self.dev)
             self.dev = ctypes.c_void_p()
 
