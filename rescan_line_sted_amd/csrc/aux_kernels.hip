@@ -153,20 +153,35 @@ __global__ void __launch_bounds__(256) k_poisson(const T* __restrict__ noiseless
 }
 
 // ---- host <-> plan staging: float64 host arrays are converted on the device -----------
-// per-frame sums of a stack [frames][n] (one workgroup per frame, wavefront shuffles), accumulated in float64
+// per-frame sums of a stack [frames][n], accumulated in float64 (wavefront shuffles).  grid (frames, chunks): workgroup (f, c) sums
+// the c-th of `chunks` equal sections of frame f into out[f * chunks + c] -- chunks == 1: the frame's sum itself.  Few large frames
+// (a 4096^2 float64 image is 134 MB: one workgroup read it at 19 GB/s, 7 ms) take kSumChunks sections and a second launch of the
+// same kernel over the partial sums; the order of the additions is fixed either way, so a frame's sum does not depend on the batch.
 template <typename T>
-__global__ void __launch_bounds__(1024) k_frame_sums(const T* __restrict__ x, size_t n, double* __restrict__ sums) {
+__global__ void __launch_bounds__(1024) k_frame_sums(const T* __restrict__ x, size_t n, double* __restrict__ out) {
     __shared__ double part[16];
+    const size_t chunks = gridDim.y, len = (n + chunks - 1) / chunks, i0 = blockIdx.y * len, i1 = i0 + len < n ? i0 + len : n;
     const T* f = x + (size_t)blockIdx.x * n;
     double v = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) v += (double)f[i];
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) v += (double)f[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x < 64) {
         v = threadIdx.x < (blockDim.x >> 6) ? part[threadIdx.x] : 0.0;
         for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (threadIdx.x == 0) sums[blockIdx.x] = v;
+        if (threadIdx.x == 0) out[(size_t)blockIdx.x * chunks + blockIdx.y] = v;
+    }
+}
+// sums[0 .. frames) <- the frames' sums; sums[frames .. frames * (1 + kSumChunks)) is scratch (aux_sums_elems)
+template <typename T>
+static void frame_sums(const T* x, size_t n, size_t frames, double* sums, hipStream_t s) {
+    if (n >= ((size_t)1 << 20) && frames * kSumChunks <= 8192) {
+        double* part = sums + frames;
+        k_frame_sums<T><<<dim3((unsigned)frames, kSumChunks), 1024, 0, s>>>(x, n, part);
+        k_frame_sums<double><<<dim3((unsigned)frames, 1), 64, 0, s>>>(part, (size_t)kSumChunks, sums);
+    } else {
+        k_frame_sums<T><<<dim3((unsigned)frames, 1), 1024, 0, s>>>(x, n, sums);
     }
 }
 
@@ -290,7 +305,7 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
 
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
                              double* sums, hipStream_t s, bool want_sums) {
-    if (target || want_sums) k_frame_sums<double><<<(unsigned)frames, 1024, 0, s>>>(src, n, sums);
+    if (target || want_sums) frame_sums<double>(src, n, frames, sums, s);
     const unsigned g = blocks_for(n * frames, 256);
     if (dtype == DT_F32) k_scale_convert<float><<<g, 256, 0, s>>>(src, (float*)dst, n, frames, target, sums);
     else k_scale_convert<double><<<g, 256, 0, s>>>(src, (double*)dst, n, frames, target, sums);
@@ -314,8 +329,8 @@ hipError_t aux_any_negative(int dtype, const void* src, size_t n, int* flag, hip
 
 hipError_t aux_image_sums(int dtype, const void* src, size_t n, size_t frames, double* sums, hipStream_t s) {
     if (frames == 0) return hipSuccess;
-    if (dtype == DT_F32) k_frame_sums<float><<<(unsigned)frames, 1024, 0, s>>>((const float*)src, n, sums);
-    else k_frame_sums<double><<<(unsigned)frames, 1024, 0, s>>>((const double*)src, n, sums);
+    if (dtype == DT_F32) frame_sums<float>((const float*)src, n, frames, sums, s);
+    else frame_sums<double>((const double*)src, n, frames, sums, s);
     return hipGetLastError();
 }
 
@@ -333,7 +348,7 @@ __global__ void k_scale_convert_indexed(const double* __restrict__ src, const un
 }
 hipError_t aux_scale_convert_indexed(int dtype, const double* src, const unsigned* idx, size_t n_unique, void* dst, size_t n, size_t frames,
                                      const double* target, double* sums, hipStream_t s) {
-    if (target) k_frame_sums<double><<<(unsigned)n_unique, 1024, 0, s>>>(src, n, sums);
+    if (target) frame_sums<double>(src, n, n_unique, sums, s);
     const unsigned g = blocks_for(n * frames, 256);
     if (dtype == DT_F32) k_scale_convert_indexed<float><<<g, 256, 0, s>>>(src, idx, (float*)dst, n, frames, target, sums);
     else k_scale_convert_indexed<double><<<g, 256, 0, s>>>(src, idx, (double*)dst, n, frames, target, sums);

@@ -21,7 +21,11 @@ hipError_t aux_poisson(int dtype, const void* noiseless, void* noisy, unsigned n
                        unsigned long long seed, int rng_kind, void* list_ws, hipStream_t s,
                        const unsigned long long* frame_seeds = nullptr, const unsigned* frame_ids = nullptr, unsigned V = 1);
 // float64 stack [frames][n] (device) -> plan dtype, each frame scaled to sum target[f]
-// (target / sums: device arrays of `frames` doubles; target == nullptr: no scaling)
+// Every `sums` argument below is device memory of aux_sums_elems(frames) doubles: the frames' sums, then scratch for the partial
+// sums of large frames (aux_kernels.hip frame_sums).
+constexpr size_t kSumChunks = 64;
+inline size_t aux_sums_elems(size_t frames) { return frames * (1 + kSumChunks); }
+// (target: device array of `frames` doubles; target == nullptr: no scaling)
 // want_sums: fill `sums` even without a target (the caller reads the frames' levels)
 hipError_t aux_scale_convert(int dtype, const double* src, void* dst, size_t n, size_t frames, const double* target,
                              double* sums, hipStream_t s, bool want_sums = false);

@@ -223,8 +223,14 @@ struct OuterCol<4608> {
     static constexpr int TWLDS = 2;   // + 15.8 KB (core) + 31.5 KB (outer)
     static constexpr int TWLDS_SPLIT = 2;
     // (float64 at 4608: 8 x 10 complex doubles per lane = 320 registers -- the workgroup-synchronous (16,16,18) x 288 kernel stays)
-    static constexpr bool value64 = false;
-    static constexpr int C64 = 2, PARK64 = 0, MIN_WAVES64 = 2;
+#ifndef RL_PARK64_4608
+#define RL_PARK64_4608 28
+#endif
+#ifndef RL_OUTER64_4608
+#define RL_OUTER64_4608 1
+#endif
+    static constexpr bool value64 = RL_OUTER64_4608 != 0;
+    static constexpr int C64 = 4, PARK64 = RL_PARK64_4608, MIN_WAVES64 = 1;
     static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 57 KB of parking space beside 39 KB of transforms (round 4: 10 values left 40-52 bytes of scratch per lane at HEAD, 14 leave 8-20)
 };
 

@@ -290,7 +290,7 @@ static hipError_t launch_row_pair_t(int mode, const void* params, unsigned gy, h
     if constexpr (WavePrivate<Cfg>::value || Q == 1) {
         const RowParams<T>& p = *static_cast<const RowParams<T>*>(params);
         const dim3 grid((unsigned)((p.ny + Q - 1) / Q), gy), block(Cfg::T * Q);
-        const size_t lds = (size_t)Q * LdsSlots<Cfg>::value * sizeof(cx<T>);
+        const size_t lds = lds_bytes<Q, T>();
         if constexpr (kColN512<T>) {   // 512-pixel rows, one view, `ratio - 1`: the specialised kernels (rowpair_body NXC / SUBC)
             if (p.nx == 512 && p.V == 1 && p.sub_one != 0 && mode != ROW_FWD) {
                 if (mode == ROW_RATIO) rl_launch(k_rowpair<RL_CFG_L, Q, ROW_RATIO, T, 512, 1>, grid, block, lds, s, p);

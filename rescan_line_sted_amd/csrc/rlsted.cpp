@@ -145,10 +145,10 @@ struct rl_deconv {
         HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (BatchSlot& sl : bslot) {
             HIP_TRY(hipHostMalloc((void**)&sl.host, slot_host_bytes(), hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void**)&sl.dev, slot_host_bytes() + 8 + (size_t)B * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&sl.dev, slot_host_bytes() + 8 + aux_sums_elems((size_t)B) * sizeof(double)));
             HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
-            bytes += slot_host_bytes() + 8 + (size_t)B * sizeof(double);
+            bytes += slot_host_bytes() + 8 + aux_sums_elems((size_t)B) * sizeof(double);
         }
         return RL_OK;
     }
@@ -579,13 +579,13 @@ struct rl_deconv {
     size_t kStageElems = 0;        // elements of the staging buffer: the plan's largest transfer, capped (a 128-square sweep plan: 4 MB)
     double* stage_dev = nullptr;   // [kStageElems] + per-frame sums / targets
     double* stage_aux = nullptr;   // [B] per-frame targets
-    double* stage_sums = nullptr;  // [B * V] per-image sums
+    double* stage_sums = nullptr;  // [B * V] per-image sums (+ scratch: aux_sums_elems)
     int ensure_stage() {
         if (stage_dev) return RL_OK;
         kStageElems = std::max(n_img(), std::min(kStageMax, (size_t)B * V * n_img()));
         HIP_TRY(hipMalloc((void**)&stage_dev, kStageElems * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&stage_aux, (size_t)B * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&stage_sums, (size_t)B * V * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&stage_sums, aux_sums_elems((size_t)B * V) * sizeof(double)));
         bytes += kStageElems * sizeof(double);
         return RL_OK;
     }

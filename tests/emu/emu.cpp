@@ -259,8 +259,10 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
     p.tw = tw.data();
     p.ny = ny; p.kx = kx; p.pitch = pitch; p.V = V; p.in_sb = in_sb; p.in_sv = in_sv;
     p.mode = mode; p.images = mode == COL_PER_IMAGE ? frames * V : frames; p.order = 1;
-    if (g_park) {   // the device's choices: 3 of the 4 x 10 values (L = 2304), 14 of the 8 x 10 (L = 4608); M = 2: 5 (for the test)
-        constexpr int PARK = M == 4 ? 3 : M == 8 ? 14 : 5;
+    // the device's choices: f32 3 of the 4 x 10 values (L = 2304), 14 of the 8 x 10 (L = 4608); float64 (g_park == 2) 10 and 24;
+    // M = 2: 5 (for the test)
+    auto parked = [&](auto park_c) {
+        constexpr int PARK = decltype(park_c)::value;
         constexpr int TWLDS = (M == 8 || C == 16) ? 2 : 1;     // the twiddles from an LDS copy (L = 4608 and the 16-column tiles of 2304: the outer table too)
         run_grid((kx + C - 1) / C, p.images, 64 * C,
                  ((size_t)C * LdsSlots<Core>::value + (size_t)PARK * 64 * C + (TWLDS > 0 ? PassTw<Core, false, 0>::TOTAL : 0) + (TWLDS > 1 ? (M - 1) * Core::L : 0)) * sizeof(cx<T>),
@@ -269,6 +271,13 @@ static int col_outer_t(const T* in, T* out, const T* psf_hat, int real_psf, int 
                      if (real_psf) colconv_outer_body<Core, M, C, T, true, COL_PER_IMAGE, PARK, TWLDS>(p, tid, bx, by, l, s);
                      else colconv_outer_body<Core, M, C, T, false, COL_PER_IMAGE, PARK, TWLDS>(p, tid, bx, by, l, s);
                  });
+    };
+    if (g_park == 1) {
+        parked(std::integral_constant<int, M == 4 ? 3 : M == 8 ? 14 : 5>{});
+        return 0;
+    }
+    if (g_park == 2) {
+        parked(std::integral_constant<int, M == 4 ? 10 : M == 8 ? 24 : 4>{});
         return 0;
     }
     run_grid((kx + C - 1) / C, p.images, 64 * C, (size_t)C * LdsSlots<Core>::value * sizeof(cx<T>),

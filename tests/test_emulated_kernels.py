@@ -358,12 +358,12 @@ def test_ratio_minus_one_l576_f32(emu):
 @pytest.mark.parametrize('Li,M,ny,kx,real_psf', [(256, 4, 900, 11, 0), (256, 2, 437, 8, 1), (576, 4, 2048, 9, 0),
                                                    (576, 4, 2001, 3, 1), (256, 8, 1900, 5, 0), (576, 8, 4096, 2, 1),
                                                    (256, 16, 1000, 21, 1)])      # (M = 16: M = 4 on 16-column tiles)
-@pytest.mark.parametrize('park', [0, 1])
+@pytest.mark.parametrize('park', [0, 1, 2])
 def test_outer_decimation_column_pass(emu, Li, M, ny, kx, real_psf, park):
     """colconv_outer_body: L = M * Li as M core transforms plus one radix-M step in registers (the f32
     column kernel of L = 1152 = 2 x 576, 2304 = 4 x 576 and 4608 = 8 x 576).  Against numpy: IFFT_y(FFT_y(x zero padded to L) * psf_hat),
     rows < ny.  park: some of the waiting core results per lane wait in LDS instead of registers (PARK: 3 of 4 x 10 used in place
-    during the radix-4 steps, 10 of 8 x 10 brought back for them) and the twiddles are read from an LDS copy -- the same values either way."""
+    during the radix-4 steps, 14 of 8 x 10 brought back for them; park = 2: the float64 kernels' 10 and 24) and the twiddles are read from an LDS copy -- the same values either way."""
     emu.emu_set_park.argtypes = [ctypes.c_int]
     L, V, frames = (4 if M == 16 else M) * Li, 2, 1
     pitch = (kx + 7) // 8 * 8

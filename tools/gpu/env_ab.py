@@ -19,9 +19,9 @@ plans = []
 for cfg in sys.argv[4:]:
     env = dict(kv.split('=') for kv in cfg.split(',') if kv)
     os.environ.update(env)
-    plan = _lib.DeconvPlan(psfs, B, n, n, dtype='f32')
-    for k in env:
-        del os.environ[k]
+    plan = _lib.DeconvPlan(psfs, B, n, n, dtype=env.pop('DTYPE', 'f32'))   # (DTYPE=f64: a key of this tool, not of the library)
+    for k in list(env) + ['DTYPE']:
+        os.environ.pop(k, None)
     plan.set_object(np.broadcast_to(obj, (B, n, n)), 5e10 * (n / 128) ** 2)
     plan.bench_cycles(20, 1, seed=1)
     plans.append(plan)
