@@ -25,6 +25,9 @@
 #ifndef RL_TILE_WIDE
 #define RL_TILE_WIDE 1        // 16-byte accesses in the column tile I/O of the compile-time-size kernels (colconv_wave_body WIDE)
 #endif
+#ifndef RL_TILE_WIDE_F64
+#define RL_TILE_WIDE_F64 0   // the two-column tile I/O in double: the host emulator only (its tests run the tile code in double)
+#endif
 #ifndef RL_CT_RESIDUAL
 #define RL_CT_RESIDUAL 1      // compact twiddles in the transforms that carry `ratio - 1` (kernels with `sub_one` at compile time)
 #endif
@@ -251,7 +254,7 @@ RL_HD void colconv_wave_body(const ColParams<T>& p, int tid, int bx, int by, cx<
     // WIDE (round 4; the compile-time-size kernels): a thread moves TWO neighbouring columns of a row with one 16-byte access (f64:
     // two) -- thread -> (row tid / (C/2) + 128 it, columns 2 (tid % (C/2)), + 1) -- half the vector-memory instructions of the
     // tile load and store for the same bytes (16 bytes per lane is the width the memory pipeline is built for).
-    constexpr bool WIDE = RL_TILE_WIDE != 0 && NYC > 0 && NYC % 128 == 0 && C % 2 == 0;
+    constexpr bool WIDE = RL_TILE_WIDE != 0 && (sizeof(T) == 4 || RL_TILE_WIDE_F64 != 0) && NYC > 0 && NYC % 128 == 0 && C % 2 == 0;
     struct alignas(2 * sizeof(cx<T>)) cx2 {
         cx<T> a, b;
     };
@@ -495,7 +498,9 @@ RL_HD void colconv_outer_body(const ColParams<T>& p, int tid, int bx, int by, cx
     // WIDE (as colconv_wave_body's): two neighbouring columns of a row per 16-byte access -- thread -> (class row tid / (C/2) + 128 it,
     // columns 2 (tid % (C/2)), + 1); x[2 it], x[2 it + 1] hold the pair
     constexpr int NYQ = NYC / M;                                    // rows of a residue class
-    constexpr bool WIDE = RL_TILE_WIDE != 0 && NYC > 0 && NYQ % 128 == 0 && C % 2 == 0 && 2 * (NYQ / 128) <= NLD;
+    // (float only: a complex double is a 16-byte access already, and the 32-byte pairs of the float64 kernel at M = 8 stayed in
+    // scratch -- 160 bytes per lane, 56 stores + 56 loads per column: 4096^2 float64 61 -> 68 frames/s without them)
+    constexpr bool WIDE = RL_TILE_WIDE != 0 && (sizeof(T) == 4 || RL_TILE_WIDE_F64 != 0) && NYC > 0 && NYQ % 128 == 0 && C % 2 == 0 && 2 * (NYQ / 128) <= NLD;
     struct alignas(2 * sizeof(cx<T>)) cx2 {
         cx<T> a, b;
     };

@@ -222,14 +222,14 @@ struct OuterCol<4608> {
 #endif
     static constexpr int TWLDS = 2;   // + 15.8 KB (core) + 31.5 KB (outer)
     static constexpr int TWLDS_SPLIT = 2;
-    // (float64 at 4608: 8 x 10 complex doubles per lane = 320 registers -- the workgroup-synchronous (16,16,18) x 288 kernel stays)
+    // float64 (end of round 4): 8 x 10 complex doubles per lane = 320 registers -- 28 of them wait in LDS, ONE 4-wave workgroup per CU
+    // at ~415 registers (accumulation registers included), 4 x 9.7 KB of transforms + 112 KB of parking space; the workgroup-
+    // synchronous (16,16,18) x 288 kernel it replaces: 66.9 -> 58.5 ms per 4 frames x 21 passes at 4096^2 (parked 20 / 24 / 28:
+    // 65.96 / 65.60 / 64.88 ms before the tile I/O change, conv_kernels.hpp WIDE)
 #ifndef RL_PARK64_4608
 #define RL_PARK64_4608 28
 #endif
-#ifndef RL_OUTER64_4608
-#define RL_OUTER64_4608 1
-#endif
-    static constexpr bool value64 = RL_OUTER64_4608 != 0;
+    static constexpr bool value64 = value;
     static constexpr int C64 = 4, PARK64 = RL_PARK64_4608, MIN_WAVES64 = 1;
     static constexpr int PARK = RL_PARK_4608;   // one workgroup per CU: 57 KB of parking space beside 39 KB of transforms (round 4: 10 values left 40-52 bytes of scratch per lane at HEAD, 14 leave 8-20)
 };

@@ -13,6 +13,7 @@
 #include <type_traits>
 #include <vector>
 
+#define RL_TILE_WIDE_F64 1   // the device runs the two-column tile I/O in float only; here its index logic is tested in double
 #include "../../rescan_line_sted_amd/csrc/conv_kernels.hpp"
 #include "../../rescan_line_sted_amd/csrc/fft_configs.hpp"
 #include "../../rescan_line_sted_amd/csrc/philox_poisson.hpp"

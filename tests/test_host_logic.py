@@ -199,7 +199,7 @@ def test_default_path_kernels_do_not_spill(tmp_path):
         for k, v in table.items():
             if 'double' in k:
                 if 'k_colconv_outer' in k:
-                    assert v == 0, (k, v)     # float64 column pass on the outer-decimation body (round 4): 218 registers, nothing spilled
+                    assert v == 0, (k, v)     # float64 column pass on the outer-decimation body (round 4): 218 registers at L = 2304, ~415 with accumulation registers at L = 4608, nothing in scratch
                 continue                      # (the other f64 kernels of the long lengths: DESIGN.md section 8, follow-ups)
             if 'k_colconv_outer' in k and re.search(r', (true|false), 0, float>', k):
                 assert v <= whole_max, (k, v)  # the whole pass (single-view plans)
