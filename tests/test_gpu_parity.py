@@ -349,6 +349,35 @@ def test_4096_tile_runs(lib, golden):
         del plan
 
 
+@pytest.mark.parametrize('ny,nx,V,B', [(4000, 37, 1, 2), (3001, 20, 2, 1), (2000, 41, 3, 2), (1500, 70, 1, 3), (4096, 24, 1, 1), (620, 3000, 1, 1)])
+def test_long_transforms_odd_shapes_vs_oracle(lib, ny, nx, V, B):
+    """The long transforms (L = 1152 / 2304 / 4608 along y, once along x) on images whose row count is not the compile-time one
+    and whose spectra do not fill whole column tiles -- float64: the outer-decimation column kernels with 2 / 4 / 8 residue
+    classes, 0 / 10 / 28 waiting values parked in LDS, rows tested one by one -- through H, H_t and two RL iterations against the
+    oracle; f32 at its tolerance.  Narrow images keep the oracle cheap."""
+    rng = np.random.default_rng(ny + nx)
+    psfs = [rng.random((1, 9, 7)) + 0.01 for _ in range(V)]
+    x = rng.random((B, ny, nx)) * 20
+    d = orc.Deconvolver(psfs)
+    Hx = d.H(x)
+    y = [rng.random((B, ny, nx)) for _ in range(V)]
+    Ht = d.H_t(y)
+    d.create_data_from_object(x, random_seed=5)
+    d.iterate()
+    d.iterate()
+    for dtype, tol in (('f64', 1e-11), ('f32', F32_TOL)):
+        plan = lib.DeconvPlan(psfs, B, ny, nx, dtype=dtype)
+        assert max(plan.info()['ly'], plan.info()['lx']) >= 1152
+        got = plan.forward(x)
+        for v in range(V):
+            assert max_rel(got[:, v], Hx[v]) < tol, (dtype, 'H', v)
+        assert max_rel(plan.adjoint(np.stack(y, axis=1)), Ht) < 5 * tol, (dtype, 'Ht')
+        plan.set_measurement(np.stack(d.noisy_measurement, axis=1))
+        plan.iterate(2)
+        assert max_rel(plan.estimate(), d.estimate) < 10 * tol, (dtype, 'RL')
+        del plan
+
+
 # ---------------------------------------------- size independent properties
 @pytest.mark.parametrize('shape', [(512, 512), (500, 317), (129, 64), (2, 3)])
 def test_operator_properties(lib, golden, shape):
