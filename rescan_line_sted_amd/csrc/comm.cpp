@@ -150,12 +150,12 @@ int rl_comm_create(rl_ctx* ctx, int rank, int world, const void* id128, rl_comm*
 
 int rl_comm_destroy(rl_comm* c) {
     if (!c) return RL_OK;
-    hipSetDevice(c->ctx->device);
-    hipStreamSynchronize(c->ctx->stream);
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) rccl()->CommDestroy(c->comm);
-    if (c->gathered) hipFree(c->gathered);
-    if (c->staging) hipFree(c->staging);
-    if (c->scalar) hipFree(c->scalar);
+    if (c->gathered) (void)hipFree(c->gathered);
+    if (c->staging) (void)hipFree(c->staging);
+    if (c->scalar) (void)hipFree(c->scalar);
     delete c;
     return RL_OK;
 }

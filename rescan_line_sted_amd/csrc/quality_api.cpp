@@ -11,7 +11,7 @@ using namespace rl;
 namespace {
 struct DevBuf {   // scoped device allocation
     void* p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
     int get(size_t bytes) {
         HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
         return RL_OK;

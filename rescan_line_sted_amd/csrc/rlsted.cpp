@@ -123,7 +123,7 @@ struct rl_deconv {
     // is staged and uploaded while chunk i iterates.  Block layout (host and device): header -- [B] float64 targets, [B] uint64
     // seeds, [B] uint32 image ids, [B] uint32 object index -- then the chunk's DISTINCT objects, [<= B][n_img] float64 (tasks that
     // share an object pointer -- a sweep's seeds -- are staged and uploaded once; only the used prefix of the block crosses PCIe);
-    // the device block is followed by [B] float64 sums.
+    // the device block is followed by the objects' float64 sums and their scratch (aux_sums_elems(B)).
     struct BatchSlot {
         char* host = nullptr;
         char* dev = nullptr;
@@ -140,16 +140,21 @@ struct rl_deconv {
     size_t slot_objects_bytes() const { return (size_t)B * n_img() * sizeof(double); }
     size_t slot_header_bytes() const { return ((size_t)B * (8 + 8 + 4 + 4) + 15) / 16 * 16; }
     size_t slot_host_bytes() const { return slot_header_bytes() + slot_objects_bytes(); }
+    bool batch_slots_ready = false;
     int ensure_batch_slots() {
-        if (copy_stream) return RL_OK;
-        HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        if (batch_slots_ready) return RL_OK;
+        // (a call that failed half way is taken up where it stopped: every resource is created once, the destructor frees what exists)
+        if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (BatchSlot& sl : bslot) {
-            HIP_TRY(hipHostMalloc((void**)&sl.host, slot_host_bytes(), hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void**)&sl.dev, slot_host_bytes() + 8 + aux_sums_elems((size_t)B) * sizeof(double)));
-            HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
-            bytes += slot_host_bytes() + 8 + aux_sums_elems((size_t)B) * sizeof(double);
+            if (!sl.host) HIP_TRY(hipHostMalloc((void**)&sl.host, slot_host_bytes(), hipHostMallocDefault));
+            if (!sl.dev) {
+                HIP_TRY(hipMalloc((void**)&sl.dev, slot_host_bytes() + 8 + aux_sums_elems((size_t)B) * sizeof(double)));
+                bytes += slot_host_bytes() + 8 + aux_sums_elems((size_t)B) * sizeof(double);
+            }
+            if (!sl.uploaded) HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+            if (!sl.freed) HIP_TRY(hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
         }
+        batch_slots_ready = true;
         return RL_OK;
     }
     hipStream_t cur() const { return active ? active : ctx->stream; }
@@ -955,10 +960,10 @@ int rl_ctx_create(int device, rl_ctx** out) {
 
 int rl_ctx_destroy(rl_ctx* c) {
     if (!c) return RL_OK;
-    hipSetDevice(c->device);
-    for (auto& kv : c->tw) hipFree(kv.second);
-    if (c->psf_work) hipFree(c->psf_work);
-    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    for (auto& kv : c->tw) (void)hipFree(kv.second);
+    if (c->psf_work) (void)hipFree(c->psf_work);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RL_OK;
 }
@@ -971,31 +976,31 @@ int rl_ctx_synchronize(rl_ctx* c) {
 
 int rl_deconv_destroy(rl_deconv* h) {
     if (!h) return RL_OK;
-    hipSetDevice(h->ctx->device);
+    (void)hipSetDevice(h->ctx->device);
     // nothing of this plan may still be running when its buffers go away (slice streams included)
-    hipStreamSynchronize(h->ctx->stream);
+    (void)hipStreamSynchronize(h->ctx->stream);
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
-        if (h->lane_stream[l]) hipStreamSynchronize(h->lane_stream[l]);
+        if (h->lane_stream[l]) (void)hipStreamSynchronize(h->lane_stream[l]);
     void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->spec_x, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
                     h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids};
     for (void* b : bufs)
-        if (b) hipFree(b);
-    if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
+        if (b) (void)hipFree(b);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     for (rl_deconv::BatchSlot& sl : h->bslot) {
-        if (sl.host) hipHostFree(sl.host);
-        if (sl.dev) hipFree(sl.dev);
-        if (sl.uploaded) hipEventDestroy(sl.uploaded);
-        if (sl.freed) hipEventDestroy(sl.freed);
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.freed) (void)hipEventDestroy(sl.freed);
     }
-    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
-    if (h->batch_out) hipFree(h->batch_out);
-    for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->fork) hipEventDestroy(h->fork);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->batch_out) (void)hipFree(h->batch_out);
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->fork) (void)hipEventDestroy(h->fork);
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l) {
-        if (h->lane_done[l]) hipEventDestroy(h->lane_done[l]);
-        if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]);
+        if (h->lane_done[l]) (void)hipEventDestroy(h->lane_done[l]);
+        if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]);
     }
     delete h;
     return RL_OK;
@@ -1051,8 +1056,8 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         hipError_t e = aux_psf_spectrum(h->dtype, (const double*)psf_dev, wx, wy, s1, h->psf_hat, h->V, h->py, h->px,
                                         h->ly, h->lx, h->kx, h->pitch, h->ty->psf_transposed[h->dtype], ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        hipFree(psf_dev);
-        hipFree(s1);
+        (void)hipFree(psf_dev);
+        (void)hipFree(s1);
         HIP_TRY(e);
         HIP_TRY(e2);
     }
