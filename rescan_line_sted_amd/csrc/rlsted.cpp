@@ -940,6 +940,13 @@ int rl_fft_length_for(int n) {
     return 0;
 }
 
+// A sweep deals its plan groups to several contexts of a GPU (sweep.py), each with a stream of its own plus its plans' slice and copy
+// streams.  The HIP runtime maps a process's streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise; with 8 the
+// small launches of neighbouring groups overlap further (BASELINE config 4, 1152 tasks: 29.7 -> 26.4-26.8 ms on 4-6 contexts,
+// profiles/r04/sweep_hw_queues.log).  The runtime reads the variable when it initialises -- at this process's first HIP call --
+// so the default is set when the library is loaded, and only if the user has not set it.
+__attribute__((constructor)) static void rl_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 int rl_ctx_create(int device, rl_ctx** out) {
     if (!out) return fail(RL_ERR_INVALID, "out is NULL");
     *out = nullptr;

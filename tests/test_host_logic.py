@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(lib.PROTOTYPES) == declared          # the ctypes table binds exactly the header
 
 
+def test_library_asks_for_eight_hardware_queues_unless_told_otherwise():
+    """Loading librlsted.so sets GPU_MAX_HW_QUEUES=8 in the process environment (the HIP runtime reads it at its first call: the
+    sweep's contexts then overlap on 8 hardware queues instead of 4, csrc/rlsted.cpp rl_runtime_defaults) and leaves a value the
+    user chose alone.  In child processes: the environment of this one is already decided."""
+    import subprocess
+    import sys
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from rescan_line_sted_amd import _lib; "
+            "g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; print(g(b'GPU_MAX_HW_QUEUES').decode())" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.check_output([sys.executable, '-c', code], env=env, text=True).strip() == '8'
+    env['GPU_MAX_HW_QUEUES'] = '2'
+    assert subprocess.check_output([sys.executable, '-c', code], env=env, text=True).strip() == '2'
+
+
 def test_no_gpu_errors_are_loud(lib):
     if lib.device_count() > 0:
         pytest.skip('a GPU is present')
