@@ -379,10 +379,13 @@ def test_long_transforms_odd_shapes_vs_oracle(lib, ny, nx, V, B):
 
 
 # ---------------------------------------------- size independent properties
-@pytest.mark.parametrize('shape', [(512, 512), (500, 317), (129, 64), (2, 3)])
-def test_operator_properties(lib, golden, shape):
+@pytest.mark.parametrize('shape,views', [((512, 512), None), ((500, 317), None), ((129, 64), None), ((2, 3), None),
+                                         ((2048, 2048), None), ((4096, 4096), 1)])
+def test_operator_properties(lib, golden, shape, views):
+    """Size-independent properties of H and H_t, up to BASELINE's full sizes (config 3: 2048 x 2048 line-rescan; config 5's
+    4096 x 4096 tile with one view: linearity, the clamp, the adjoint identity, H_t(ones) = ones, the energy bound."""
     ny, nx = shape
-    psf = golden('g8_fig2_psfs')['1p5x_lr/line_sted_psfs'][:, 0]
+    psf = golden('g8_fig2_psfs')['1p5x_lr/line_sted_psfs'][:views, 0]
     psfs = [p[None] for p in psf]
     rng = np.random.default_rng(ny * 1000 + nx)
     plan = lib.DeconvPlan(psfs, 2, ny, nx, dtype='f64')
