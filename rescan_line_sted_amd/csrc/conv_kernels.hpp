@@ -58,8 +58,18 @@ RL_HD double rl_div(double a, double b) { return a / b; }
 // transforms stamped onto the update factor (it is not blurred by any later convolution, so every iteration adds to
 // it) shrinks with the residual.  Same arithmetic count, identical in exact arithmetic; the clamp (ref:587) acts on
 // the view sum, as in the fused-views mode.
+// v: the model's prediction H(est) as it comes out of the inverse transform; the reference clamps it at 0 (ref:575) and divides
+// (ref:524).  In exact arithmetic it is positive wherever the estimate and the PSFs are; a transform resolves it to eps * max
+// only, so in a dark region wider than the PSF -- estimate ~ 1e-9 after the first iteration, ref:510 -- an f32 plan's
+// prediction is rounding noise of either sign (a float64 plan's: from 1e-16 of the maximum down).  The reference then divides by
+// zero: inf, NaN through the next fftconvolve, the whole frame lost.  Here a pixel whose prediction is not positive is NEUTRAL --
+// ratio 1, residual 0: it neither raises nor lowers the estimate -- and every value stays finite
+// (tests/test_gpu_parity.py::test_dark_background_narrow_psf_stays_finite).  Where v > 0 the clamp is the identity.
 template <typename T>
-RL_HD T rl_ratio(T meas, T e, bool sub_one) { return rl_div(sub_one ? meas - e : meas, e); }
+RL_HD T rl_ratio(T meas, T v, bool sub_one) {
+    const T q = rl_div(sub_one ? meas - v : meas, v);
+    return v > (T)0 ? q : (sub_one ? (T)0 : (T)1);
+}
 // a: sum over the views of the back-transformed values -- clamped per view (plain mode) or raw (sub_one)
 template <typename T>
 RL_HD T rl_update_factor(T a, T nrm, bool sub_one) {
@@ -1032,8 +1042,8 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (inx && ok0) dst[(size_t)r0 * p.nx + i] = v[s].re > (T)0 ? v[s].re : (T)0;
                 if (inx && ok1) dst[(size_t)r1 * p.nx + i] = v[s].im > (T)0 ? v[s].im : (T)0;
             } else if constexpr (MODE == ROW_RATIO) {
-                if (inx && ok0) z.re = rl_ratio(pre[PREFETCH ? s : 0].re, rl_clamp0(v[s].re), p.sub_one != 0);
-                if (inx && ok1) z.im = rl_ratio(pre[PREFETCH ? s : 0].im, rl_clamp0(v[s].im), p.sub_one != 0);
+                if (inx && ok0) z.re = rl_ratio(pre[PREFETCH ? s : 0].re, v[s].re, p.sub_one != 0);
+                if (inx && ok1) z.im = rl_ratio(pre[PREFETCH ? s : 0].im, v[s].im, p.sub_one != 0);
             } else if constexpr (MODE == ROW_UPDATE) {
                 T* __restrict__ est = p.dst + (size_t)by * rimg;
                 const bool sub = p.sub_one != 0;
@@ -1203,8 +1213,8 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
             cx<T> z = mk<T>((T)0, (T)0);
             const bool sub = SUBC < 0 ? p.sub_one != 0 : SUBC != 0;
             if constexpr (MODE == ROW_RATIO) {
-                z.re = inx ? rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub) : (T)0;
-                z.im = inx && ok1 ? rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub) : (T)0;
+                z.re = inx ? rl_ratio(pre[s].re, v[s].re, sub) : (T)0;
+                z.im = inx && ok1 ? rl_ratio(pre[s].im, v[s].im, sub) : (T)0;
             } else {
                 z.re = inx ? pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s].re, sub) : (T)0;
                 z.im = inx && ok1 ? pre[s].im * rl_update_factor(sub ? v[s].im : rl_clamp0(v[s].im), nrm[s].im, sub) : (T)0;
@@ -1366,7 +1376,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
             z = pre[s];
         } else {
             if constexpr (MODE == ROW_RATIO) {
-                if (inx) z = mk<T>(rl_ratio(pre[s].re, rl_clamp0(v[s].re), sub), rl_ratio(pre[s].im, rl_clamp0(v[s].im), sub));
+                if (inx) z = mk<T>(rl_ratio(pre[s].re, v[s].re, sub), rl_ratio(pre[s].im, v[s].im, sub));
             } else {
                 if (inx) {
                     z = mk<T>(pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s], sub),

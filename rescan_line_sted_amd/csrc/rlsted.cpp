@@ -1413,10 +1413,9 @@ int rl_deconv_set_measurement(rl_deconv* h, const double* noisy) {
         h->meas_level.assign((size_t)h->B, 0.0);
         for (size_t i = 0; i < sums.size(); ++i) h->meas_level[i / h->V] += sums[i];
         h->choose_loop(h->meas_level);
-        RL_TRY(h->scan_meas_negative());
+        RL_TRY(h->scan_meas_negative());      // (an uploaded measurement may hold negative pixels: sub())
     }
     h->meas_external = false;
-    h->meas_negative = false;   // (Poisson draws + 1e-9)
     h->have_meas = true;
     h->est_ready = false;
     return RL_OK;

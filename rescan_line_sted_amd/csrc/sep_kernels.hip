@@ -55,7 +55,7 @@ enum SepMode { SEP_STORE = 0, SEP_RATIO = 1, SEP_SUM = 2, SEP_UPDATE = 3 };
 
 // column stencil of the row-pass results + epilogue.  Images of `tmp` are [frame*V + view].
 //   SEP_STORE : dst[frame*V+view] = max(conv, 0)                                   (H / noiseless)
-//   SEP_RATIO : dst[frame*V+view] = aux[frame*V+view] / max(conv, 0)               (measurement / H(est))
+//   SEP_RATIO : dst[frame*V+view] = aux[frame*V+view] / max(conv, 0)               (measurement / H(est); 1 where conv <= 0)
 //   SEP_SUM   : dst[frame] = sum_v max(conv_v, 0) (/ norm if norm)                 (H_t, normaliser)
 //   SEP_UPDATE: dst[frame] *= sum_v max(conv_v, 0) / norm                          (est *= H_t(ratio) / H_t(1))
 template <typename T, int MODE>
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_sep_cols(const T* __restrict__ tmp, con
         const size_t o = ((size_t)frame * ny + y) * nx + x;
         const size_t pix = (size_t)y * nx + x;
         if (MODE == SEP_STORE) dst[o] = acc[k];
-        else if (MODE == SEP_RATIO) dst[o] = aux[o] / acc[k];
+        else if (MODE == SEP_RATIO) dst[o] = acc[k] > (T)0 ? aux[o] / acc[k] : (T)1;   // (a prediction that is not positive: neutral pixel, conv_kernels.hpp rl_ratio)
         else if (MODE == SEP_SUM) dst[o] = norm ? acc[k] / norm[pix] : acc[k];
         else dst[o] = dst[o] * (acc[k] / norm[pix]);
     }
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_sep2d(const T* __restrict__ in, const T
                     const int y = y0 + g * 8 + j;
                     if (x < nx && y < ny) {
                         const size_t o = (((size_t)frame * V + view) * ny + y) * nx + x;
-                        dst[o] = MODE == SEP_STORE ? a : aux[o] / a;
+                        dst[o] = MODE == SEP_STORE ? a : (a > (T)0 ? aux[o] / a : (T)1);   // (neutral where the prediction is not positive: rl_ratio)
                     }
                 }
             }

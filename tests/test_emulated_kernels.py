@@ -196,6 +196,36 @@ def test_row_forward_is_rfft_of_padded_rows(emu):
         assert max_rel(out[:, :, :pl.kx], ref) < 1e-14
 
 
+@pytest.mark.parametrize('L,nx', [(64, 40), (192, 130), (576, 512)])
+@pytest.mark.parametrize('sub_one', [0, 1])
+def test_ratio_is_neutral_where_the_prediction_is_not_positive(emu, L, nx, sub_one):
+    """conv_kernels.hpp rl_ratio: the reference clamps H(est) at 0 and divides (ref:575, 524) -- inf, then NaN through the next
+    convolution.  The kernels make such a pixel neutral: ratio 1 (residual 0 with `ratio - 1`).  ROW_RATIO on rows whose
+    prediction is positive, zero and negative by turns, against numpy with the same rule; every value finite."""
+    emu.emu_set_sub_one.argtypes = [ctypes.c_int]
+    ny = 6
+    pl = EmuPlan(emu, [np.ones((1, 1, 1))], ny, nx, 64, L)
+    rng = np.random.default_rng(L + sub_one)
+    pred = rng.random((1, ny, nx)) + 0.5
+    pred[0, :, ::3] = -0.125                    # rounding noise below zero (an exact 0 comes back from the transform as noise of either
+    pred[0, :, 1::7] = -0.25                    # sign, ~1e-16: then meas / noise ~ 1e15 is what the rule -- and the reference -- give)
+    meas = rng.random((1, ny, nx)) * 5 + 1e-9
+    sin = pl.spec(1)
+    sin[...] = 0
+    sin[:, :, :pl.kx] = np.fft.rfft(pred, n=L, axis=2) / L         # the inverse row pass is unnormalised
+    out = pl.spec(1)
+    try:
+        emu.emu_set_sub_one(sub_one)
+        pl.row(ROW_RATIO, 1, spec_in=sin, spec_out=out, src=_slack(meas))
+    finally:
+        emu.emu_set_sub_one(0)
+    ok = pred > 0
+    ratio = np.where(ok, (meas - pred if sub_one else meas) / np.where(ok, pred, 1.0), 0.0 if sub_one else 1.0)
+    back = np.fft.irfft(out[:, :, :pl.kx], n=L, axis=2)[:, :, :nx]
+    assert np.isfinite(out[:, :, :pl.kx]).all()
+    assert max_rel(back, ratio) < 1e-13
+
+
 def test_column_pass_is_circular_convolution_along_y(emu):
     rng = np.random.default_rng(2)
     for Ly, ny in ((64, 37), (192, 130), (256, 161)):
