@@ -540,6 +540,74 @@ def test_random_shapes_vs_oracle(lib, seed):
         del plan
 
 
+@pytest.mark.parametrize('seed', range(int(os.environ.get('RLSTED_FUZZ_SEEDS', '8'))))
+def test_random_hard_cases_vs_oracle(lib, seed, monkeypatch):
+    """The soak test's second half (RLSTED_FUZZ_SEEDS): what test_random_shapes_vs_oracle does not draw -- the long transforms
+    (L = 1152 / 2304 / 4608 along one axis, the other kept narrow for the oracle), SPARSE objects at a low dose (most pixels count
+    zero photons: the neutral-pixel rule of conv_kernels.hpp rl_ratio in every row body), the frame-pair loop against the
+    per-frame loop, odd batches, and rl_batch_run against set_object / simulate / iterate.  Well-posed seeds compare the iterates
+    with the oracle; every seed must stay finite and non-negative."""
+    rng = np.random.default_rng(50000 + seed)
+    long_axis = int(rng.integers(0, 3))                   # 0: no long axis, 1: y, 2: x
+    big = int(rng.choice([1152, 2304, 4608]))
+    py, px = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+    hy, hx = max((py - 1) // 2, py - 1 - (py - 1) // 2), max((px - 1) // 2, px - 1 - (px - 1) // 2)
+    small = lambda h: int(rng.integers(2, 150))
+    ny = int(rng.integers(big // 2 + 1, big - hy + 1)) if long_axis == 1 else small(hy)
+    nx = int(rng.integers(big // 2 + 1, big - hx + 1)) if long_axis == 2 else small(hx)
+    if long_axis:                                         # keep the oracle (and the upload) cheap
+        if long_axis == 1:
+            nx = min(nx, 48)
+        else:
+            ny = min(ny, 48)
+    V = int(rng.integers(1, 5))
+    B = int(rng.integers(1, 6))
+    psfs = [rng.random((1, py, px)) + 0.01 for _ in range(V)]
+    sparse = bool(rng.integers(0, 2))
+    x = rng.random((B, ny, nx)) * 20
+    if sparse:
+        x *= rng.random((B, ny, nx)) < 0.03
+        x[:, ny // 2, nx // 2] += 5.0                     # (never an empty frame)
+    brightness = float(rng.choice([30.0, 3e3, 3e6])) * ny * nx / 100
+    d = orc.Deconvolver(psfs)
+    d.create_data_from_object(x, brightness, random_seed=seed)
+    meas = np.stack(d.noisy_measurement, axis=1)
+    K = 3
+    well_posed = True
+    d.estimate = np.ones_like(x)                          # (what the first iterate() starts from, ref:521-522)
+    with np.errstate(all='ignore'):
+        for _ in range(K):
+            pred = d.H(d.estimate)
+            lo, hi = min(float(p.min()) for p in pred), max(float(p.max()) for p in pred)
+            well_posed = well_posed and np.isfinite(lo) and lo > 1e-4 * hi
+            d.iterate()
+    results = {}
+    for dtype, tol in (('f64', 1e-10), ('f32', 3e-5)):
+        for pair in ('0', '1'):
+            monkeypatch.setenv('RLSTED_PAIR', pair)
+            plan = lib.DeconvPlan(psfs, B, ny, nx, dtype=dtype)
+            monkeypatch.delenv('RLSTED_PAIR')
+            plan.set_measurement(meas)
+            plan.iterate(K)
+            est = plan.estimate()
+            assert np.isfinite(est).all() and est.min() >= 0 and est.max() > 0, (dtype, pair, ny, nx, py, px, V, B, sparse)
+            if well_posed:
+                assert max_rel(est, d.estimate) < tol, (dtype, pair, 'RL', ny, nx, py, px, V, B, sparse, brightness)
+            results[dtype, pair] = est
+            del plan
+        if well_posed:                                    # the two loops of one arithmetic type agree much closer than with the oracle
+            assert max_rel(results[dtype, '1'], results[dtype, '0']) < (1e-11 if dtype == 'f64' else 2e-5)
+    # the batch call: scale, H, keyed Poisson draws, K iterations in one enqueue -- the same frames as the stepwise calls with the same keys
+    if ny * nx <= 200 * 200:
+        plan = lib.DeconvPlan(psfs, B, ny, nx, dtype='f64')
+        seeds, ids = [int(s) for s in rng.integers(0, 2 ** 40, B)], [int(i) for i in rng.integers(0, 1000, B)]
+        got = plan.batch_run(list(x), brightness, seeds, ids, K)
+        plan.set_object(x, brightness)
+        plan.simulate_keyed(seeds, ids)
+        plan.iterate(K)
+        assert np.array_equal(got, plan.estimate()), ('batch', ny, nx, V, B)
+
+
 def test_edge_cases(lib):
     rng = np.random.default_rng(0)
     # PSF larger than the image, 1-pixel image, single row / column
