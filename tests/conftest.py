@@ -47,3 +47,10 @@ def max_rel(a, b):
     a = np.asarray(a, dtype=np.complex128 if cplx else np.float64)
     b = np.asarray(b, dtype=np.complex128 if cplx else np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def fuzz_seeds(default):
+    """Seeds of a randomised test: `default` of them in the suite, RLSTED_FUZZ_SEEDS of them in a soak run
+    (RLSTED_FUZZ_SEEDS=5000 python -m pytest tests -m gpu -k random)."""
+    import os
+    return range(int(os.environ.get('RLSTED_FUZZ_SEEDS', default)))

@@ -4,7 +4,7 @@ reference's arithmetic (line_sted_tools.py:520-531, 567-594).  Both strategies (
 import numpy as np
 import pytest
 
-from conftest import max_rel
+from conftest import max_rel, fuzz_seeds
 from oracle import line_sted_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +29,7 @@ def rl_step(views, meas, est):
     return out
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', fuzz_seeds(8))
 @pytest.mark.parametrize('strategy', ['fft', 'separable'])
 def test_random_call_sequences_follow_the_reference(lib, strategy, seed):
     rng = np.random.default_rng(1000 + seed)

@@ -4,7 +4,7 @@ multi-view record_data -> load_data_from_tif round trip."""
 import numpy as np
 import pytest
 
-from conftest import max_rel
+from conftest import max_rel, fuzz_seeds
 from oracle import line_sted_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -121,7 +121,7 @@ def test_pinned_host_arrays_and_out_argument(st, views, obj):
     del frames, out, got                 # the blocks are released with their last views
 
 
-@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('seed', fuzz_seeds(6))
 def test_random_method_sequences_match_the_reference_class(st, seed, tmp_path):
     """The mirror class and the oracle's restatement of the reference class driven through the same random
     sequence of calls (new data after iterations, estimate assignment, H / H_t on the data's and on other

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import max_rel
+from conftest import max_rel, fuzz_seeds
 from oracle import line_sted_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -492,7 +492,7 @@ def test_device_poisson_bit_exact_vs_oracle_twin(lib, golden):
             assert np.array_equal(got, want), (dtype, tb)
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('RLSTED_FUZZ_SEEDS', '12'))))     # (a soak run: RLSTED_FUZZ_SEEDS=300)
+@pytest.mark.parametrize('seed', fuzz_seeds(12))     # (a soak run: RLSTED_FUZZ_SEEDS=300)
 def test_random_shapes_vs_oracle(lib, seed):
     """Random image / PSF shapes (odd sizes, even PSFs, 1-10 views, every transform length
     up to 1152) through H, H_t and two RL iterations, f64 against the oracle at 1e-11 and
@@ -540,7 +540,7 @@ def test_random_shapes_vs_oracle(lib, seed):
         del plan
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('RLSTED_FUZZ_SEEDS', '8'))))
+@pytest.mark.parametrize('seed', fuzz_seeds(8))
 def test_random_hard_cases_vs_oracle(lib, seed, monkeypatch):
     """The soak test's second half (RLSTED_FUZZ_SEEDS): what test_random_shapes_vs_oracle does not draw -- the long transforms
     (L = 1152 / 2304 / 4608 along one axis, the other kept narrow for the oracle), SPARSE objects at a low dose (most pixels count

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import max_rel
+from conftest import max_rel, fuzz_seeds
 from oracle import line_sted_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -77,6 +77,42 @@ def test_generate_psfs_general_shapes_vs_oracle(st):
             assert set(got) == set(ref)
             for k in ref:
                 assert max_rel(got[k], ref[k]) < 1e-12, (shape, psf_type, k)
+
+
+@pytest.mark.parametrize('seed', fuzz_seeds(8))
+def test_random_psf_parameters_vs_oracle(st, seed):
+    """Soak test of the PSF half (RLSTED_FUZZ_SEEDS): generate_psfs on random shapes (odd / even / non-square, small enough for
+    the 'reflect' boundary to wrap more than once), blur widths and brightnesses, point and line, and psf_report's scalars and
+    PSFs at random operating points -- device against the oracle."""
+    rng = np.random.default_rng(70000 + seed)
+    shape = (1, int(rng.integers(5, 90)), int(rng.integers(5, 90)))
+    sigma = float(rng.uniform(0.6, 7.0))
+    exc, dep = float(rng.uniform(0.02, 3.0)), float(rng.choice([0.0, rng.uniform(0.1, 40.0)]))
+    psf_type = ('point', 'line')[int(rng.integers(0, 2))]
+    if dep == 0.0:                                   # (no depletion: ref:204-207 divides by its maximum)
+        dep = 0.5
+    if psf_type == 'line' and shape[2] < 5 * sigma:  # the line's row must fit the grid: a truncated row fits to a width of ~0 and a
+        shape = (1, shape[1], int(5 * sigma) + 1)    # rescan ratio of 1e4 ... 1e5 (the C ABI refuses ratios above 4096, INTEGRATION.md section 4)
+    got = st.generate_psfs(shape, exc, dep, sigma, psf_type, verbose=False)
+    ref = orc.generate_psfs(shape, exc, dep, sigma, psf_type)
+    ref.pop('line_rescan_ratio', None)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert max_rel(got[k], ref[k]) < 1e-10, (shape, psf_type, sigma, exc, dep, k)
+    steps = float(rng.uniform(4.0, 16.0))
+    pulses = int(rng.choice([1, 1, 2, 5]))
+    r = st.psf_report(psf_type, exc, dep, steps, pulses, verbose=False)
+    o = orc.psf_report(psf_type, exc, dep, steps, pulses)
+    o.pop('line_rescan_ratio', None)                 # (an extra of the oracle: the integer rescan ratio of ref:252-256)
+    assert set(r) == set(o)
+    for k in o:
+        if k == 'psfs':
+            for name, v in o['psfs'].items():
+                assert max_rel(r['psfs'][name], v) < 1e-11, (psf_type, steps, exc, dep, pulses, name)
+        elif k.startswith('resolution'):
+            assert r[k] == pytest.approx(o[k], rel=2e-6), (psf_type, steps, exc, dep, pulses, k)
+        else:
+            assert r[k] == pytest.approx(o[k], rel=1e-11, abs=1e-300), (psf_type, steps, exc, dep, pulses, k)
 
 
 def test_gaussian_filter_vs_oracle():

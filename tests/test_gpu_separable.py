@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import max_rel
+from conftest import max_rel, fuzz_seeds
 from oracle import line_sted_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -129,7 +129,7 @@ def test_strategy_choice(lib, golden):
     assert not plan_with(lib, 2, planes([blob]), 1, 64, 64).strategy()['separable']
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', fuzz_seeds(12))
 def test_separable_random_small_cases_vs_oracle(lib, seed):
     """Automatic choice (py + px <= 16) on ragged shapes: images smaller than a tile, smaller than the PSF,
     1-pixel rows / columns, several views and frames -- H, H_t and three iterations against the oracle."""
