@@ -147,6 +147,16 @@ int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements
  * the rounding error of a bright partner.  Any of the pointers may be NULL.                                  */
 int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* split_column_pass, int* frame_pairs);
 
+/* Predictions the plan could not resolve.  iterate divides the measurement by H(estimate) clamped at 0 (line_sted_tools.py:575,
+ * 524); in exact arithmetic that prediction is positive, but a transform resolves a value to eps * the frame's maximum only, so
+ * on sparse emitters over a black background the predictions of the dark region are rounding noise of either sign -- below 1e-7
+ * of the maximum for an f32 plan, 1e-16 for a float64 plan (and for the reference, which then divides by zero: inf, nan, the
+ * frame lost).  The kernels treat a pixel whose prediction is not positive as neutral (ratio 1) and count it: *count = the lanes
+ * of the FFT path's ratio launches that met such a pixel inside the image since the plan was created or the counter last reset
+ * (reset != 0 clears it).  0 on data the plan's arithmetic resolves; an f32 plan that counts should be a float64 plan -- its
+ * estimates stay finite and non-negative but are no longer within 1e-5 of the float64 result.  Synchronises the plan's stream. */
+int rl_deconv_unresolved(rl_deconv* h, unsigned long long* count, int reset);
+
 /* Plan geometry: frames per plan, views per frame, image shape.                */
 int rl_deconv_dims(const rl_deconv* h, int* batch, int* n_psf, int* ny, int* nx);
 

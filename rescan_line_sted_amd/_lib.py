@@ -51,6 +51,7 @@ PROTOTYPES = {
     'rl_host_alloc': (_i, [_c.c_size_t, _c.POINTER(_vp)]),
     'rl_host_free': (_i, [_vp]),
     'rl_deconv_strategy': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    'rl_deconv_unresolved': (_i, [_vp, _c.POINTER(_c.c_uint64), _i]),
     'rl_deconv_dims': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     'rl_batch_run': (_i, [_vp, _vp, _i, _i, _i, _dp]),
     'rl_batch_submit': (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
@@ -232,6 +233,15 @@ class DeconvPlan:
 
     def simulate(self, seed=0, rng=RNG_PHILOX):
         check(lib.rl_deconv_simulate(self.handle, rng, _c.c_uint64(seed)))
+
+    def unresolved(self, reset=False):
+        """Lanes of the ratio launches that met a prediction H(estimate) <= 0 inside the image since the plan was created (or the
+        counter last reset): 0 on data the plan's arithmetic resolves.  An f32 plan that counts -- sparse emitters on a black
+        background, a PSF narrower than the gaps -- stays finite but is no longer within 1e-5 of the float64 result
+        (include/rlsted.h rl_deconv_unresolved)."""
+        n = _c.c_uint64(0)
+        check(lib.rl_deconv_unresolved(self.handle, _c.byref(n), 1 if reset else 0))
+        return int(n.value)
 
     def set_measurement(self, noisy):
         noisy = as_f64(noisy).reshape(self.B, self.V, self.ny, self.nx)

@@ -65,10 +65,24 @@ RL_HD double rl_div(double a, double b) { return a / b; }
 // zero: inf, NaN through the next fftconvolve, the whole frame lost.  Here a pixel whose prediction is not positive is NEUTRAL --
 // ratio 1, residual 0: it neither raises nor lowers the estimate -- and every value stays finite
 // (tests/test_gpu_parity.py::test_dark_background_narrow_psf_stays_finite).  Where v > 0 the clamp is the identity.
+// `unresolved` collects, per lane, whether any pixel INSIDE the image met such a prediction: the row bodies add the lanes up in
+// RowParams::unresolved (rl_count_unresolved), the plan reports the count (rl_deconv_unresolved) -- zero on data whose predictions
+// the plan's arithmetic resolves; an f32 plan that counts should be a float64 plan.
 template <typename T>
-RL_HD T rl_ratio(T meas, T v, bool sub_one) {
+RL_HD T rl_ratio(T meas, T v, bool sub_one, bool in_image, bool& unresolved) {
     const T q = rl_div(sub_one ? meas - v : meas, v);
-    return v > (T)0 ? q : (sub_one ? (T)0 : (T)1);
+    const bool pos = v > (T)0;
+    unresolved = unresolved || (in_image && !pos);
+    return pos ? q : (sub_one ? (T)0 : (T)1);
+}
+RL_HD void rl_count_unresolved(unsigned long long* counter, bool lane_met_one) {
+    if (counter != nullptr && lane_met_one) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(counter, 1ull);
+#else
+        __atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED);
+#endif
+    }
 }
 // a: sum over the views of the back-transformed values -- clamped per view (plain mode) or raw (sub_one)
 template <typename T>
@@ -870,6 +884,7 @@ struct RowParams {
     int in_mod = 0;
     int sub_one = 0;        // ROW_RATIO stores rowFFT(ratio - 1), ROW_UPDATE multiplies by max(1 + acc / norm, 0): see rl_ratio
     float qscale = 1.0f;    // storage-precision study builds only (rl_spec_round)
+    unsigned long long* unresolved = nullptr;   // ROW_RATIO: + the lanes that met a prediction <= 0 inside the image (rl_ratio); nullptr: not counted
 };
 
 // ONEV: compile-time single view (n_psf == 1): no accumulator registers, no view loop.  PRESUM (with ONEV, ROW_UPDATE): p.V
@@ -1023,6 +1038,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     }
 
     // pointwise stage on elements i = j + r*NBF (column index), rows r0 (.re), r1 (.im)
+    bool unresolved = false;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int j = t + nb * TT;
@@ -1042,8 +1058,8 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
                 if (inx && ok0) dst[(size_t)r0 * p.nx + i] = v[s].re > (T)0 ? v[s].re : (T)0;
                 if (inx && ok1) dst[(size_t)r1 * p.nx + i] = v[s].im > (T)0 ? v[s].im : (T)0;
             } else if constexpr (MODE == ROW_RATIO) {
-                if (inx && ok0) z.re = rl_ratio(pre[PREFETCH ? s : 0].re, v[s].re, p.sub_one != 0);
-                if (inx && ok1) z.im = rl_ratio(pre[PREFETCH ? s : 0].im, v[s].im, p.sub_one != 0);
+                if (inx && ok0) z.re = rl_ratio(pre[PREFETCH ? s : 0].re, v[s].re, p.sub_one != 0, true, unresolved);
+                if (inx && ok1) z.im = rl_ratio(pre[PREFETCH ? s : 0].im, v[s].im, p.sub_one != 0, true, unresolved);
             } else if constexpr (MODE == ROW_UPDATE) {
                 T* __restrict__ est = p.dst + (size_t)by * rimg;
                 const bool sub = p.sub_one != 0;
@@ -1075,6 +1091,7 @@ RL_HD void rowpass_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
     }
 
     rl_stamp(sync, 3);   // pointwise stage done (its operands have arrived)
+    if constexpr (MODE == ROW_RATIO) rl_count_unresolved(p.unresolved, unresolved);
     if constexpr (MODE == ROW_FWD || MODE == ROW_RATIO || MODE == ROW_UPDATE) {
         run_passes<Cfg, false, 0, true>(v, tl, t, view_lds, p.tw, sync);
         rl_stamp(sync, 4);
@@ -1202,6 +1219,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
 #pragma unroll
             for (int r = 0; r < R; ++r) nrm[nb * R + r] = mk<T>(n0[t + (nb * 64 + r * NBF)], n1[t + (nb * 64 + r * NBF)]);
     }
+    bool unresolved = false;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int j = (int)t + nb * 64;
@@ -1213,8 +1231,8 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
             cx<T> z = mk<T>((T)0, (T)0);
             const bool sub = SUBC < 0 ? p.sub_one != 0 : SUBC != 0;
             if constexpr (MODE == ROW_RATIO) {
-                z.re = inx ? rl_ratio(pre[s].re, v[s].re, sub) : (T)0;
-                z.im = inx && ok1 ? rl_ratio(pre[s].im, v[s].im, sub) : (T)0;
+                z.re = inx ? rl_ratio(pre[s].re, v[s].re, sub, inx, unresolved) : (T)0;
+                z.im = inx && ok1 ? rl_ratio(pre[s].im, v[s].im, sub, inx && ok1, unresolved) : (T)0;
             } else {
                 z.re = inx ? pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s].re, sub) : (T)0;
                 z.im = inx && ok1 ? pre[s].im * rl_update_factor(sub ? v[s].im : rl_clamp0(v[s].im), nrm[s].im, sub) : (T)0;
@@ -1225,6 +1243,7 @@ RL_HD void row_item(const RowParams<T>& p, unsigned t, int by, int r0, RowSpectr
         }
     }
     rl_stamp(sync, 3);
+    if constexpr (MODE == ROW_RATIO) rl_count_unresolved(p.unresolved, unresolved);
     run_passes<Cfg, false, 0, true, (SUBC == 1 && MODE == ROW_RATIO) ? RL_CT_RESIDUAL : 0>(v, tl, tl_, view_lds, tw, sync);
     rl_stamp(sync, 4);
     // natural-order spectrum to LDS, then split it into the two rows' half spectra
@@ -1366,6 +1385,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         // (SUBC == 1: the update's inverse transform carries H_t(ratio - 1), the ratio kernel's forward transform ratio - 1)
         run_passes<Cfg, true, 0, true, (SUBC == 1 && MODE == ROW_UPDATE) ? RL_CT_RESIDUAL : 0>(v, tl, t, view_lds, p.tw, sync);
     }
+    bool unresolved = false;
 #pragma unroll
     for (int s = 0; s < NB * R; ++s) {
         const int nb = s / R, r = s % R;
@@ -1375,8 +1395,8 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         if constexpr (MODE == ROW_FWD) {
             z = pre[s];
         } else {
-            if constexpr (MODE == ROW_RATIO) {
-                if (inx) z = mk<T>(rl_ratio(pre[s].re, v[s].re, sub), rl_ratio(pre[s].im, v[s].im, sub));
+            if constexpr (MODE == ROW_RATIO) {      // (.im of a phantom partner -- an odd batch's last pair -- is not a frame: not counted)
+                if (inx) z = mk<T>(rl_ratio(pre[s].re, v[s].re, sub, true, unresolved), rl_ratio(pre[s].im, v[s].im, sub, okb, unresolved));
             } else {
                 if (inx) {
                     z = mk<T>(pre[s].re * rl_update_factor(sub ? v[s].re : rl_clamp0(v[s].re), nrm[s], sub),
@@ -1388,6 +1408,7 @@ RL_HD void rowpair_body(const RowParams<T>& p, int tid, int bx, int by, cx<T>* l
         }
         v[s] = z;
     }
+    if constexpr (MODE == ROW_RATIO) rl_count_unresolved(p.unresolved, unresolved);
     if constexpr (MODE == ROW_UPDATE) {
         if (p.spec_out == nullptr) return;   // last iteration of a run: nobody reads the new estimate's spectrum (uniform)
     }

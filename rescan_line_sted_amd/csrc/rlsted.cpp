@@ -92,6 +92,9 @@ struct rl_deconv {
     // through rl_deconv_set_measurement) therefore runs the plain arithmetic with the per-view clamp; so does RLSTED_FUSE_VIEWS=0,
     // the switch that asks for the reference's per-view clamp.
     bool meas_negative = false;
+    // lanes of the ROW_RATIO launches that met a prediction H(est) <= 0 inside the image (conv_kernels.hpp rl_ratio: such a pixel is
+    // neutral); device counter, read by rl_deconv_unresolved.  Zero on data whose predictions the plan's arithmetic resolves.
+    unsigned long long* unresolved = nullptr;
     bool in_rl_loop = false;   // set by iterate_chunk: only there do the H_t column launches carry `ratio - 1` (rl_adjoint's input is an image)
     bool sub() const { return sub_one && !(V > 1 && meas_negative); }
     void* obj = nullptr;       // [B][ny][nx]
@@ -276,6 +279,7 @@ struct rl_deconv {
         RowParams<T> p;
         p.in_mod = in_mod;
         p.sub_one = sub() ? 1 : 0;
+        p.unresolved = unresolved;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -531,6 +535,7 @@ struct rl_deconv {
         RowParams<T> p;
         p.in_mod = in_mod;
         p.sub_one = sub() ? 1 : 0;
+        p.unresolved = unresolved;
         p.qscale = mode == ROW_RATIO ? q_ratio : q_est;
         p.spec_in = (const cx<T>*)spec_in;
         p.spec_out = (cx<T>*)spec_out;
@@ -989,7 +994,7 @@ int rl_deconv_destroy(rl_deconv* h) {
     for (int l = 0; l < rl_deconv::kMaxLanes; ++l)
         if (h->lane_stream[l]) (void)hipStreamSynchronize(h->lane_stream[l]);
     void* bufs[] = {h->psf_hat_pair, h->psf_hat_pair_re, h->spec_ones_pair, h->sep_u, h->sep_v, h->sep_uf, h->sep_vf, h->spec_ones, h->psf_hat_re, h->psf_hat, h->spec_a, h->spec_b, h->spec_x, h->obj, h->noiseless, h->meas, h->est, h->norm, h->scratch,
-                    h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids};
+                    h->stage_dev, h->stage_aux, h->stage_sums, h->slice_ws, h->key_seeds, h->key_ids, h->unresolved};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
@@ -1048,6 +1053,8 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
         HIP_TRY(hipMemsetAsync(static_cast<char*>(*r.p) + r.n, 0, RL_STREAM_SLACK, ctx->stream));
         h->bytes += r.n + RL_STREAM_SLACK;
     }
+    HIP_TRY(hipMalloc((void**)&h->unresolved, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(h->unresolved, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
 
@@ -1565,6 +1572,16 @@ int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectru
     if (separable) *separable = h->sep ? 1 : 0;
     if (real_psf_spectrum) *real_psf_spectrum = h->psf_hat_re ? 1 : 0;
     if (split_column_pass) *split_column_pass = !h->sep && !h->pair && h->col_split() ? 1 : 0;
+    return RL_OK;
+}
+
+int rl_deconv_unresolved(rl_deconv* h, unsigned long long* count, int reset) {
+    if (!h || !count) return fail(RL_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    // (the slices of a run are joined into the context's stream before a run returns: everything counted so far is ordered before this copy)
+    HIP_TRY(hipMemcpyAsync(count, h->unresolved, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->ctx->stream));
+    if (reset) HIP_TRY(hipMemsetAsync(h->unresolved, 0, sizeof(unsigned long long), h->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));
     return RL_OK;
 }
 

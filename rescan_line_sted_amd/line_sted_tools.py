@@ -228,6 +228,22 @@ class Deconvolver:
             buf = None
         self._estimate = plan.estimate(out=buf)
         self._estimate_stale = False
+        self._warn_unresolved(plan)
+
+    def _warn_unresolved(self, plan):
+        """Once per Deconvolver, when the estimate is fetched: the iterations met predictions H(estimate) <= 0 (a dark region whose
+        prediction is below eps * the frame's maximum).  The reference divides by the clamped zero there -- inf, then nan; the
+        kernels kept the pixels neutral and every value finite."""
+        if getattr(self, '_unresolved_warned', False):
+            return
+        n = plan.unresolved()
+        if n:
+            import warnings
+            self._unresolved_warned = True
+            warnings.warn('%d row segments of the Richardson-Lucy iterations met a prediction H(estimate) <= 0: the reference would '
+                          'have divided by zero (inf, nan); these pixels were kept neutral.%s' % (
+                              n, ' The float32 plan (RLSTED_DTYPE=f32) cannot resolve the predictions of dark regions: use the float64 '
+                              'default for such data.' if self.dtype == 'f32' else ''), RuntimeWarning, stacklevel=3)
 
     @property
     def estimate(self):

@@ -214,3 +214,27 @@ def test_psfs_with_depth(st, tmp_path):
     d = st.Deconvolver([rng.random((3, 5, 5))], str(tmp_path) + '/', verbose=False)
     with pytest.raises(NotImplementedError, match='couples the 2 z slices'):
         d.H(rng.random((2, 20, 20)))
+
+
+def test_deconvolver_warns_when_predictions_are_unresolved(st, tmp_path):
+    """Sparse emitters, a narrow PSF, float32 arithmetic: the mirror's estimate stays finite and the first fetch warns that the
+    iterations met predictions the plan could not resolve (the reference's arithmetic: 1 / 0); the float64 default does not."""
+    import warnings
+    rng = np.random.default_rng(3)
+    obj = np.zeros((1, 128, 128))
+    obj[0, rng.integers(8, 120, 12), rng.integers(8, 120, 12)] = 1.0
+    yy, xx = np.mgrid[-4:5, -4:5]
+    u, w = 0.866 * xx + 0.5 * yy, -0.5 * xx + 0.866 * yy
+    psf = np.exp(-0.5 * ((u / 1.6) ** 2 + (w / 0.8) ** 2))[None]
+    for dtype, expect in (('f32', True), ('f64', False)):
+        d = st.Deconvolver([psf], output_prefix=str(tmp_path / dtype) + '_', verbose=False, dtype=dtype)
+        d.create_data_from_object(obj, total_brightness=2e3, random_seed=1)
+        for _ in range(6):
+            d.iterate()
+        with warnings.catch_warnings(record=True) as w_:
+            warnings.simplefilter('always')
+            est = d.estimate
+            again = d.estimate                               # (once per Deconvolver)
+        assert np.isfinite(est).all() and est.max() > 0 and again is est
+        hits = [x for x in w_ if 'H(estimate) <= 0' in str(x.message)]
+        assert len(hits) == (1 if expect else 0), (dtype, [str(x.message) for x in w_])

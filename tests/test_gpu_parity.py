@@ -416,6 +416,7 @@ def test_rl_preserves_flux_and_positivity(lib, golden, astronaut512):
     plan.iterate(20)
     est = plan.estimate()[0]
     assert np.isfinite(est).all() and est.min() >= 0
+    assert plan.unresolved() == 0                         # the BASELINE workload: every prediction is resolved by the f32 transforms
     # RL with H_t(ones)-normalisation conserves the measured counts through H
     again = plan.forward(est[None])[0, 0]
     meas = plan.measurement()[0, 0]
@@ -451,6 +452,7 @@ def test_dark_background_narrow_psf_stays_finite(lib):
     p64.iterate(K)
     e64 = p64.estimate()
     assert np.isfinite(e64).all()
+    assert p64.unresolved() == 0                          # float64 resolves these predictions (14 decades)
     print('f64 plan vs oracle: %.2e; smallest prediction / largest: %.1e' % (max_rel(e64, d.estimate), d.H(d.estimate)[0].min() / d.H(d.estimate)[0].max()))
     assert max_rel(e64, d.estimate) < 1e-8
     for pair in ('1', '0'):
@@ -464,6 +466,8 @@ def test_dark_background_narrow_psf_stays_finite(lib):
         p32.iterate(K)
         e32 = p32.estimate()
         assert np.isfinite(e32).all() and e32.min() >= 0 and e32.max() > 0
+        assert p32.unresolved() > 0                        # ... and the plan says so: rl_deconv_unresolved
+        assert p32.unresolved(reset=True) > 0 and p32.unresolved() == 0
         for b in range(2):
             err = max_rel(e32[b], e64[b])
             print('f32 (pairs %s) frame %d vs f64 plan: %.2e' % (pair, b, err))
