@@ -454,6 +454,8 @@ def fig2_sweep_leg(comm, rank, world, device, stub):
            'partition': 'sharding.partition_groups: whole (PSF set, shape) plan groups per rank, largest first; cost = pixels x views x '
                         '(2 + 2K) per task + %d frames of set-up per plan' % sweep.PLAN_SETUP_FRAMES}
     out.update(sharding.partition_stats(shards, costs, keys))
+    if not stub:     # (after the timed region) predictions H(est) <= 0 this rank's plans met: 0 = the f32 transforms resolve the sweep's data
+        out['unresolved_predictions_this_rank'] = sweep.unresolved_total()
     if rank == 0:
         assert flat.shape[0] == sum(pix) and np.isfinite(flat).all()
         out['frames_on_root'] = len([i for sh in shards for i in sh])
@@ -632,6 +634,8 @@ def main():
     }
     if rank == 0 and not args.no_accuracy and not stub and size == 512:   # (the oracle needs minutes per 2048^2 frame)
         out['accuracy'] = accuracy(plan, psf, size, args.dtype)
+        # predictions H(est) <= 0 met by the ratio kernels in everything this plan ran (rl_deconv_unresolved): 0 = the f32 transforms resolve this workload
+        out['accuracy']['unresolved_predictions'] = plan.unresolved()
     if cpu is not None:
         out['cpu_baseline'] = cpu
     # further shapes in the same record, a few steps each (single-process runs only -- the N-rank runs measure the

@@ -91,6 +91,12 @@ def clear_plans():
     _set_keys.clear()
 
 
+def unresolved_total(reset=False):
+    """Predictions H(est) <= 0 the kept plans met in their sweeps so far (DeconvPlan.unresolved, include/rlsted.h
+    rl_deconv_unresolved): 0 on data the plans' arithmetic resolves.  Synchronises the plans' contexts."""
+    return sum(plan.unresolved(reset=reset) for plan in _plans.values())
+
+
 class DeviceResults:
     """The estimates of a list of tasks in ONE device buffer (rl_device_alloc): image i at element offsets[i], shape shapes[i],
     arithmetic type `dtype` -- unpadded, in task order.  What rl_batch_submit writes and rl_comm_gather_device sends."""
@@ -240,6 +246,8 @@ def figure_2_sweep(objects, psf_sets, seeds, iterations, total_brightness=5e10, 
         info.update(sharding.partition_stats(shards, costs, task_groups(tasks, objects)))
     if comm is not None and hasattr(comm, 'gather_device'):
         res = run_tasks_device(mine, objects, psf_sets, iterations, total_brightness, dtype, device)
+        if info is not None:
+            info['unresolved_predictions_this_rank'] = unresolved_total(reset=True)
         flat = comm.gather_device(res, pix, 0)       # root: host float64, rank-major; others: None
         res.free()
     else:
