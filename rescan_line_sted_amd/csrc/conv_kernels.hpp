@@ -76,13 +76,14 @@ RL_HD T rl_ratio(T meas, T v, bool sub_one, bool in_image, bool& unresolved) {
     return pos ? q : (sub_one ? (T)0 : (T)1);
 }
 RL_HD void rl_count_unresolved(unsigned long long* counter, bool lane_met_one) {
-    if (counter != nullptr && lane_met_one) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        atomicAdd(counter, 1ull);
+    // one atomic per wavefront that met any (a dark frame has them in half its lanes: 64 atomics on one address per wave otherwise)
+    const unsigned long long met = __ballot(lane_met_one);
+    if (counter != nullptr && met != 0 && (int)(threadIdx.x & 63u) == __ffsll((long long)met) - 1)
+        atomicAdd(counter, (unsigned long long)__popcll(met));
 #else
-        __atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED);
+    if (counter != nullptr && lane_met_one) __atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED);
 #endif
-    }
 }
 // a: sum over the views of the back-transformed values -- clamped per view (plain mode) or raw (sub_one)
 template <typename T>
