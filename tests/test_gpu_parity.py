@@ -496,6 +496,37 @@ def test_device_poisson_bit_exact_vs_oracle_twin(lib, golden):
             assert np.array_equal(got, want), (dtype, tb)
 
 
+@pytest.mark.parametrize('seed', fuzz_seeds(6))
+def test_random_rates_poisson_bit_exact_vs_twin(lib, seed):
+    """The device sampler on arbitrary rates (a 1 x 1 PSF: the rates are the object): log-uniform from 1e-12 to 1e15, the
+    lam = 10 switch of the two methods from both sides, exact zeros, whole dark or whole bright tiles of the kernel's 2048-pixel
+    work lists, random shapes and batch sizes -- bit for bit the numpy twin on the rates the device reports."""
+    from oracle import philox_poisson as pp
+    rng = np.random.default_rng(31000 + seed)
+    ny, nx, B = int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 5))
+    lam = 10.0 ** rng.uniform(-12, 15, (B, ny, nx))
+    pick = rng.random((B, ny, nx))
+    lam[pick < 0.10] = 0.0
+    lam[(pick >= 0.10) & (pick < 0.20)] = 10.0 * (1 + rng.choice([-1e-15, 0.0, 1e-15, -1e-7, 1e-7], int(((pick >= 0.10) & (pick < 0.20)).sum())))
+    lam[(pick >= 0.20) & (pick < 0.45)] = rng.uniform(0.0, 40.0, int(((pick >= 0.20) & (pick < 0.45)).sum()))
+    flat = lam.reshape(-1)
+    if flat.size > 5000:                                  # whole tiles of one kind
+        flat[:2048] = rng.uniform(0.01, 9.9, 2048)
+        flat[2048:4096] = rng.uniform(1e3, 1e6, 2048)
+    for dtype in ('f64', 'f32'):
+        plan = lib.DeconvPlan([np.ones((1, 1, 1))], B, ny, nx, dtype=dtype)
+        plan.set_object(lam, None)
+        key = int(rng.integers(0, 2 ** 62))
+        plan.simulate(seed=key)
+        rates = plan.noiseless().reshape(-1, ny, nx)
+        assert np.abs(rates - lam).max() <= 1e-6 * lam.max()          # (H with a 1 x 1 PSF: the object up to the plan's rounding)
+        want = pp.noisy_measurement(rates, key)
+        if dtype == 'f32':
+            want = want.astype(np.float32).astype(np.float64)
+        assert np.array_equal(plan.measurement().reshape(-1, ny, nx), want), (dtype, ny, nx, B)
+        del plan
+
+
 @pytest.mark.parametrize('seed', fuzz_seeds(12))     # (a soak run: RLSTED_FUZZ_SEEDS=300)
 def test_random_shapes_vs_oracle(lib, seed):
     """Random image / PSF shapes (odd sizes, even PSFs, 1-10 views, every transform length
