@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import figure3_oracle as f3
+from conftest import fuzz_seeds
 from test_fig3_oracle import check_case, run_case
 
 pytestmark = pytest.mark.gpu
@@ -67,3 +68,29 @@ def test_other_shapes_vs_oracle(fig3, imaging_type, n_orient):
         for x, y in zip(a[:7], b[:7]):
             assert np.abs(x - y).max() < 1e-10
         assert a[7:] == b[7:]
+
+
+@pytest.mark.parametrize('seed', fuzz_seeds(4))
+def test_random_simulate_imaging_vs_oracle(fig3, seed):
+    """Soak test of simulate_imaging (RLSTED_FUZZ_SEEDS): random object shapes, imaging types, PSF widths, non-integer resolution
+    improvements, orientations, pulses per position and paddings -- device against the CPU oracle, frame by frame."""
+    rng = np.random.default_rng(41000 + seed)
+    imaging_type = ('descan_point', 'nondescan_multipoint', 'descan_line', 'rescan_line')[int(rng.integers(0, 4))]
+    line = imaging_type.endswith('line')
+    ny, nx = int(rng.integers(12, 44)), int(rng.integers(12, 44))
+    obj = rng.random((1, ny, nx)) + 1e-6
+    n_orient = int(rng.integers(1, 4)) if line else 1
+    pad = int(rng.integers(3, 12)) if n_orient == 1 else int(0.45 * max(ny, nx)) + int(rng.integers(0, 3))
+    psf_width = float(rng.uniform(4.0, 11.0))
+    R = float(rng.choice([1.0, 1.5, 2.0, rng.uniform(1.0, 3.0)]))
+    psf_width = max(psf_width, 2.2 * R)                # (the scan step round(psf_width / (4 R)) must not be 0: fig3:102 would divide by it)
+    pulses = int(rng.integers(1, 4))
+    want, got = [], []
+    f3.simulate_imaging(obj, imaging_type, psf_width, R, n_orient, pulses, pad, lambda rot, pos, *a: want.append((rot, pos, a)))
+    device_simulate(fig3)(obj, imaging_type, psf_width, R, n_orient, pulses, pad, lambda rot, pos, *a: got.append((rot, pos, a)))
+    case = (imaging_type, ny, nx, n_orient, pad, psf_width, R, pulses)
+    assert [(int(r), p) for r, p, _ in got] == [(int(r), p) for r, p, _ in want], case
+    for (_, _, a), (_, _, b) in zip(got, want):
+        for x, y in zip(a[:7], b[:7]):
+            assert np.abs(x - y).max() < 1e-10, case
+        assert a[7:] == b[7:], case
