@@ -287,6 +287,9 @@ int rl_psf_report_batch(rl_ctx* ctx, int n_sets, const double* params, double* r
  * rotation about the centre as scipy.ndimage.rotate(order=3, reshape=False), then
  * clipped to [0, 1.1 * max(in)].  Host in / out, float64.                       */
 int rl_rotate_psf(rl_ctx* ctx, const double* in, double* out, int ny, int nx, double degrees);
+/* The same for a stack [nz][ny][nx] in one call: every plane rotated in its plane, all of them clipped to
+ * [0, 1.1 * max(in)] with the maximum of the WHOLE array, as the script's np.clip does (fig2:271).      */
+int rl_rotate_psf_stack(rl_ctx* ctx, const double* in, double* out, int nz, int ny, int nx, double degrees);
 
 /* ---- reconstruction quality (line_sted_tools.py:539-547, line_sted_figure_2.py:353-390) ----
  * out[i] = f(|fftshift(fft2(x[i]))| * scale) for n_img real images [n_img][ny][nx] of any

@@ -77,6 +77,7 @@ PROTOTYPES = {
     'rl_psf_generate': (_i, [_vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp, _dp]),
     'rl_psf_generate_line_extras': (_i, [_vp, _i, _i, _c.c_double, _c.c_double, _c.c_double, _i, _dp, _dp]),
     'rl_rotate_psf': (_i, [_vp, _dp, _dp, _i, _i, _c.c_double]),
+    'rl_rotate_psf_stack': (_i, [_vp, _dp, _dp, _i, _i, _i, _c.c_double]),
     'rl_psf_report': (_i, [_vp, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _dp, _dp]),
     'rl_psf_report_batch': (_i, [_vp, _i, _dp, _dp, _c.POINTER(_dp)]),
     'rl_fft2_magnitude': (_i, [_vp, _dp, _i, _i, _i, _c.c_double, _i, _dp]),

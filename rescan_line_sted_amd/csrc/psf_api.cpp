@@ -80,15 +80,23 @@ int rl_gaussian_filter(rl_ctx* ctx, const double* in, double* out, int nz, int n
 // rotate of line_sted_figure_2.py:264-272 for one (ny, nx) plane: cubic-spline rotation
 // about the centre (scipy.ndimage.rotate, reshape=False), clipped to [0, 1.1*max(in)].
 int rl_rotate_psf(rl_ctx* ctx, const double* in, double* out, int ny, int nx, double degrees) {
+    return rl_rotate_psf_stack(ctx, in, out, 1, ny, nx, degrees);
+}
+
+int rl_rotate_psf_stack(rl_ctx* ctx, const double* in, double* out, int nz, int ny, int nx, double degrees) {
     if (!ctx || !in || !out) return fail(RL_ERR_INVALID, "NULL argument");
-    if (ny < 1 || nx < 1) return fail(RL_ERR_INVALID, "non-positive shape");
-    HIP_TRY(hipSetDevice(ctx->device));
+    if (nz < 1 || ny < 1 || nx < 1) return fail(RL_ERR_INVALID, "non-positive shape");
     const size_t n = (size_t)ny * nx;
-    double* work = nullptr;
-    RL_TRY(ctx->psf_workspace(3 * n + 8, &work));
-    HIP_TRY(hipMemcpyAsync(work, in, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(psf_spline_rotate(work, work + n, work + 2 * n, work + 3 * n, ny, nx, degrees, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out, work + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if ((size_t)nz * n > (size_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "stack too large");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* work = nullptr;                     // [nz][n] in, [n] spline coefficients, [nz][n] out, the clip level
+    RL_TRY(ctx->psf_workspace((2 * (size_t)nz + 1) * n + 8, &work));
+    double *d_in = work, *d_coef = work + (size_t)nz * n, *d_out = d_coef + n, *d_max = d_out + (size_t)nz * n;
+    HIP_TRY(hipMemcpyAsync(d_in, in, (size_t)nz * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int z = 0; z < nz; ++z)                // the clip level is the maximum of the WHOLE array (fig2:271), taken with the first plane
+        HIP_TRY(psf_spline_rotate(d_in + (size_t)z * n, d_coef, d_out + (size_t)z * n, d_max, ny, nx, degrees, ctx->stream,
+                                  z == 0 ? (int)((size_t)nz * n) : 0));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)nz * n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RL_OK;
 }

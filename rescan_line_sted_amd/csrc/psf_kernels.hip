@@ -364,11 +364,13 @@ hipError_t psf_rescan(const double* sted_row, const double* w, int radius, const
 
 // in: [ny][nx] device; work: [ny][nx] device scratch (receives the spline coefficients);
 // vmax: device scalar scratch
+// max_count: the values (from `in` on) whose maximum sets the clip level -- the plane's ny * nx, or a whole stack's (fig2:271 clips
+// at 1.1 * the ARRAY's maximum); 0: *vmax is already there
 hipError_t psf_spline_rotate(const double* in, double* work, double* out, double* vmax, int ny, int nx,
-                             double degrees, hipStream_t s) {
+                             double degrees, hipStream_t s, int max_count) {
     hipError_t e = hipMemcpyAsync(work, in, (size_t)ny * nx * sizeof(double), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return e;
-    k_reduce<<<1, 1024, 0, s>>>(in, ny * nx, 1, 0, vmax);
+    if (max_count > 0) k_reduce<<<1, 1024, 0, s>>>(in, max_count, 1, 0, vmax);
     k_spline_prefilter<<<nblk(nx), 256, 0, s>>>(work, ny, nx, 0);
     k_spline_prefilter<<<nblk(ny), 256, 0, s>>>(work, ny, nx, 1);
     const double th = degrees * 0.017453292519943295769236907684886;

@@ -15,7 +15,7 @@ hipError_t psf_stage2(const double* exc, double* dep, const double* maxes, doubl
 hipError_t psf_rescan(const double* sted_row, const double* w, int radius, const double* ry, const double* rx, int ny,
                       int nx, int ratio, double* b0, double* cumu, double* descan, double* rescan, hipStream_t s);
 hipError_t psf_spline_rotate(const double* in, double* work, double* out, double* vmax, int ny, int nx,
-                             double degrees, hipStream_t s);
+                             double degrees, hipStream_t s, int max_count);
 }  // namespace rl
 
 // ---- batched PSF pipeline (rl_psf_report_batch): one launch per stage over all parameter sets ----

@@ -412,8 +412,7 @@ def rotate(x, degrees):
         return np.rot90(np.squeeze(x)).reshape(x.shape)
     x = as_f64(x)
     out = np.empty_like(x)
-    for z in range(x.shape[0]):
-        check(lib.rl_rotate_psf(_ctx().handle, ptr(x[z]), ptr(out[z]), x.shape[1], x.shape[2], float(degrees)))
+    check(lib.rl_rotate_psf_stack(_ctx().handle, ptr(x), ptr(out), x.shape[0], x.shape[1], x.shape[2], float(degrees)))
     return out
 
 

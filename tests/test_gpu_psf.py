@@ -115,6 +115,35 @@ def test_random_psf_parameters_vs_oracle(st, seed):
             assert r[k] == pytest.approx(o[k], rel=1e-11, abs=1e-300), (psf_type, steps, exc, dep, pulses, k)
 
 
+@pytest.mark.parametrize('seed', fuzz_seeds(6))
+def test_random_rotations_filters_and_quality_metrics_vs_oracle(seed):
+    """Soak test of the widened rows (RLSTED_FUZZ_SEEDS): the spline rotation of PSF stacks (any angle, odd / even / non-square
+    planes), gaussian_filter with per-axis widths, get_width, the Fourier-error metrics and the radial error profile -- device
+    against the oracle."""
+    from rescan_line_sted_amd import psf, quality
+    rng = np.random.default_rng(52000 + seed)
+    ny, nx = int(rng.integers(5, 120)), int(rng.integers(5, 120))
+    x = rng.random((int(rng.integers(1, 4)), ny, nx))          # (stacks too: fig2:271 clips at the ARRAY's maximum)
+    x = x * rng.uniform(0.2, 3.0, (x.shape[0], 1, 1))
+    deg = float(rng.choice([0.0, 90.0, -90.0, 180.0, 45.0, rng.uniform(-180, 180)]))
+    assert np.abs(psf.rotate(x, deg) - orc.rotate(x, deg)).max() < 1e-11, (ny, nx, deg)
+    sig = tuple(float(v) for v in rng.choice([0.0, 0.7, 1.9, 3.3, 6.5], 3))
+    assert max_rel(psf.gaussian_filter(x, sig), orc.gaussian_filter(x, sig)) < 1e-12, (ny, nx, sig)
+    n = int(rng.integers(9, 200))
+    t = np.arange(n) - n / 2 + rng.uniform(-2, 2)
+    row = rng.uniform(0.2, 5) * np.exp(-0.5 * (t / rng.uniform(0.8, n / 8)) ** 2) + rng.random(n) * 1e-3
+    assert psf.get_width(row)[0] == pytest.approx(orc.get_width(row)[0], rel=1e-6), n
+    sy, sx = int(rng.integers(4, 150)), int(rng.integers(4, 150))
+    est, obj = rng.random((sy, sx)) * 10, rng.random((sy, sx)) * 10
+    assert max_rel(quality.fourier_error(est, obj), orc.fourier_error(est, obj)) < 1e-11, (sy, sx)
+    hist = np.stack([est, est * 0.5 + obj * 0.5, obj + 1e-3])
+    assert max_rel(quality.ft_error_history(hist, obj), orc.ft_error_history(hist, obj)) < 1e-11, (sy, sx)
+    ang, rad, smp = float(rng.uniform(0, 180)), float(rng.uniform(0.05, 0.45)), int(rng.integers(10, 400))
+    got = quality.error_vs_spatial_frequency(est, obj, ang, rad, smp)
+    want = orc.error_vs_spatial_frequency(est, obj, ang, rad, smp)
+    assert max_rel(np.asarray(got), want) < 1e-9, (sy, sx, ang, rad, smp)
+
+
 def test_gaussian_filter_vs_oracle():
     from rescan_line_sted_amd import psf
     rng = np.random.default_rng(3)
