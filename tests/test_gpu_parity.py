@@ -287,6 +287,41 @@ def test_bench_cycle_equals_simulate_then_iterate(lib, golden, astronaut512, lan
     assert np.array_equal(a.estimate(), b.estimate())
 
 
+@pytest.mark.parametrize('seed', fuzz_seeds(6))
+def test_random_schedules_bench_cycle_equals_stepwise_calls(lib, seed, monkeypatch):
+    """Soak test of the schedule (RLSTED_FUZZ_SEEDS): random batch sizes, iteration counts, slice sizes (RLSTED_CHUNK_MB down to
+    one frame per slice), 1-4 slices in flight, 1-3 views, f32 / f64, pair loop or per-frame loop, dense or sparse objects -- the
+    cycle bench.py times leaves bit for bit what simulate + iterate over the whole batch leave, back to back cycles included."""
+    rng = np.random.default_rng(81000 + seed)
+    ny, nx = int(rng.integers(20, 200)), int(rng.integers(20, 200))
+    V, B, K = int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(0, 6))
+    dtype = ('f32', 'f64')[int(rng.integers(0, 2))]
+    psfs = [rng.random((1, int(rng.integers(1, 16)), int(rng.integers(1, 16)))) + 0.01 for _ in range(V)]
+    objs = rng.random((B, ny, nx)) * 50
+    if rng.integers(0, 3) == 0:
+        objs *= rng.random((B, ny, nx)) < 0.05
+        objs[:, 0, 0] += 1.0
+    frame_mb = ny * nx * 4 * 8 / 1e6
+    monkeypatch.setenv('RLSTED_LANES', str(int(rng.integers(1, 5))))
+    monkeypatch.setenv('RLSTED_CHUNK_MB', '%g' % max(frame_mb * float(rng.choice([0.5, 2, 5, 1000])), 1e-3))
+    monkeypatch.setenv('RLSTED_PAIR', str(int(rng.integers(0, 2))))
+    brightness = float(rng.choice([50.0, 1e4, 1e8])) * ny * nx
+    cycles = int(rng.integers(1, 4))
+    a = lib.DeconvPlan(psfs, B, ny, nx, dtype=dtype)
+    a.set_object(objs, brightness)
+    a.bench_cycles(K, cycles, seed=100 + seed)
+    b = lib.DeconvPlan(psfs, B, ny, nx, dtype=dtype)
+    b.set_object(objs, brightness)
+    b.simulate(seed=100 + seed + cycles - 1)
+    if K > 0:
+        b.iterate(K)
+    case = (ny, nx, V, B, K, dtype, cycles, a.strategy())
+    assert np.array_equal(a.noiseless(), b.noiseless()), case
+    assert np.array_equal(a.measurement(), b.measurement()), case
+    if K > 0:
+        assert np.array_equal(a.estimate(), b.estimate()), case
+
+
 # ------------------------------------- BASELINE configs 3 and 5: large images
 def test_2048_line_rescan_batch_vs_oracle(lib, golden):
     """Config 3 shape: synthetic 2048x2048 random object, line-rescan (4 views), a
