@@ -53,19 +53,24 @@ PLAN_CACHE_MAX = 128
 _plans = {}
 
 
-_set_keys = {}      # id(list of PSF arrays) -> (the list, its arrays, per-array (sum, sum of squares), (digest, stack))
+_set_keys = {}      # id(list of PSF arrays) -> (the list, its arrays, per-array (sum, sum of squares), (digest, views))
 
 
 def _psf_set_key(psfs):
-    """(sha1 of the PSF stack, the stack).  Hashing 18 sets of up to ten 107 x 107 float64 PSFs is milliseconds per sweep -- as much
+    """(sha1 of the PSF set, its views as (1, py, px) float64 arrays).  Hashing 18 sets of up to ten 107 x 107 float64 PSFs is milliseconds per sweep -- as much
     as the device needs for a quarter of it -- so a set that is the SAME list of the SAME arrays as last time, with unchanged sums and
     sums of squares (an in-place edit shows there), is not hashed again."""
     ent = _set_keys.get(id(psfs))
     probe = tuple((float(np.sum(p)), float(np.square(p).sum())) for p in psfs)     # (no BLAS call: its thread pool costs more than the sums)
     if ent is not None and ent[0] is psfs and len(ent[1]) == len(psfs) and all(a is b for a, b in zip(ent[1], psfs)) and ent[2] == probe:
         return ent[3]
-    stack = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).reshape((1,) + np.shape(p)[-2:]) for p in psfs]))
-    val = (hashlib.sha1(stack.tobytes()).hexdigest(), stack)
+    # (the views of a set may differ in shape -- DeconvPlan embeds them in a common one -- so the key covers shapes and values)
+    views = [np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape((1,) + np.shape(p)[-2:])) for p in psfs]
+    h = hashlib.sha1()
+    for v in views:
+        h.update(repr(v.shape).encode())
+        h.update(v.tobytes())
+    val = (h.hexdigest(), views)
     if len(_set_keys) > 4 * PLAN_CACHE_MAX:
         _set_keys.clear()
     _set_keys[id(psfs)] = (psfs, list(psfs), probe, val)
@@ -75,11 +80,11 @@ def _psf_set_key(psfs):
 def plan_for(psfs, batch, shape, dtype='f32', device=0, stream=0):
     """The plan of a (PSF set, image shape, batch): built on first use, kept for the next sweep (the reference builds its
     Deconvolvers once per figure too, line_sted_figure_2.py:39-45).  `stream`: which of the device's contexts it lives on."""
-    digest, stack = _psf_set_key(psfs)
-    key = (digest, stack.shape, int(batch), tuple(shape), dtype, device, stream)
+    digest, views = _psf_set_key(psfs)
+    key = (digest, len(views), int(batch), tuple(shape), dtype, device, stream)
     plan = _plans.pop(key, None)
     if plan is None:
-        plan = DeconvPlan([p[None] for p in stack], batch, shape[0], shape[1], dtype=dtype, device=device, stream=stream)
+        plan = DeconvPlan(views, batch, shape[0], shape[1], dtype=dtype, device=device, stream=stream)
         while len(_plans) >= PLAN_CACHE_MAX:
             _plans.pop(next(iter(_plans)))          # the least recently used one
     _plans[key] = plan
