@@ -51,7 +51,7 @@ def partition_groups(keys, costs, world_size, setup_frames=0.0, split_at=128, mi
     pieces = []
     for k in sorted(groups, key=repr):
         idx = groups[k]
-        n_pieces = 1 if len(idx) < split_at else len(idx) // min_piece
+        n_pieces = 1 if len(idx) < split_at else max(1, len(idx) // max(1, min_piece))
         for part in np.array_split(np.asarray(idx), n_pieces):
             part = [int(i) for i in part]
             c = float(costs[part].sum())

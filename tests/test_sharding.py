@@ -54,6 +54,37 @@ def test_partition_by_plan_group():
     assert sharding.partition_groups([], [], 3) == [[], [], []]
 
 
+def test_partitions_of_random_task_sets_are_complete_and_deterministic():
+    """sharding.partition / partition_groups on random task sets, costs, world sizes and cut parameters: every task exactly once,
+    the same answer twice, no group below the cut size on two ranks, no rank loaded beyond the ideal share plus the largest piece."""
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        n_groups, world = int(rng.integers(0, 30)), int(rng.integers(1, 12))
+        keys, costs = [], []
+        for g in range(n_groups):
+            n = int(rng.integers(1, 400))
+            keys += [('g%d' % g, (int(rng.integers(1, 4)),))] * n
+            costs += [float(rng.uniform(0.1, 50))] * n
+        order = rng.permutation(len(keys))
+        keys, costs = [keys[i] for i in order], [costs[i] for i in order]
+        split_at, min_piece = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        setup = float(rng.choice([0.0, 24.0]))
+        shards = sharding.partition_groups(keys, costs, world, setup_frames=setup, split_at=split_at, min_piece=min_piece)
+        assert len(shards) == world and sorted(i for s in shards for i in s) == list(range(len(keys)))
+        assert shards == sharding.partition_groups(keys, costs, world, setup_frames=setup, split_at=split_at, min_piece=min_piece)
+        sizes = {}
+        for k in keys:
+            sizes[k] = sizes.get(k, 0) + 1
+        for k, n in sizes.items():
+            if n < split_at:
+                assert sum(1 for s in shards if any(keys[i] == k for i in s)) == 1, (trial, k)
+        plain = sharding.partition(costs, world)
+        assert sorted(i for s in plain for i in s) == list(range(len(costs)))
+        if costs:
+            load = [sum(costs[i] for i in s) for s in plain]
+            assert max(load) <= sum(costs) / world + max(costs) + 1e-9
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
