@@ -51,6 +51,7 @@ def max_rel(a, b):
 
 def fuzz_seeds(default):
     """Seeds of a randomised test: `default` of them in the suite, RLSTED_FUZZ_SEEDS of them in a soak run
-    (RLSTED_FUZZ_SEEDS=5000 python -m pytest tests -m gpu -k random)."""
+    (RLSTED_FUZZ_SEEDS=5000 python -m pytest tests -m gpu -k random; RLSTED_FUZZ_FIRST=5000 for the next 5000)."""
     import os
-    return range(int(os.environ.get('RLSTED_FUZZ_SEEDS', default)))
+    first = int(os.environ.get('RLSTED_FUZZ_FIRST', 0))          # (a later soak run continues where the last one stopped)
+    return range(first, first + int(os.environ.get('RLSTED_FUZZ_SEEDS', default)))
