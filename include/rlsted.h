@@ -154,7 +154,9 @@ int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectru
  * frame lost).  The kernels treat a pixel whose prediction is not positive as neutral (ratio 1) and count it: *count = the lanes
  * of the FFT path's ratio launches that met such a pixel inside the image since the plan was created or the counter last reset
  * (reset != 0 clears it).  0 on data the plan's arithmetic resolves; an f32 plan that counts should be a float64 plan -- its
- * estimates stay finite and non-negative but are no longer within 1e-5 of the float64 result.  Synchronises the plan's stream. */
+ * estimates stay finite and non-negative but are no longer within 1e-5 of the float64 result.  The count is a sufficient sign, not
+ * a necessary one: rounding noise that happens to be positive everywhere is not counted (a frame of isolated photons, well below
+ * one per pixel, can pass with 0).  Synchronises the plan's stream.                                                              */
 int rl_deconv_unresolved(rl_deconv* h, unsigned long long* count, int reset);
 
 /* Plan geometry: frames per plan, views per frame, image shape.                */
