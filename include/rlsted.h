@@ -133,8 +133,10 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
  * loads may read and discard): never write there, never assume the next buffer starts right behind. */
 int rl_deconv_device_ptr(rl_deconv* h, int which, void** ptr, size_t* n_elements, int* dtype);
 
-/* Convolution strategy the plan chose for its PSF set: separable != 0: every view
+/* Convolution strategy the plan chose for its PSF set: separable == 1: every view
  * is rank 1 (p = u v^T; the 0 / 90 degree line PSFs) and small, H / H_t run as direct row + column stencils;
+ * separable == 2: the views are small but not rank 1 and H / H_t run as a direct 2-D stencil (py * px multiply-adds
+ * per pixel; RLSTED_DIRECT) -- like the separable form it keeps the relative accuracy of a dark region's prediction;
  * otherwise the FFT path, with real_psf_spectrum != 0 when the (point-symmetric) PSFs' spectra are real and
  * the column kernels multiply by their real parts alone; split_column_pass != 0: a multi-view f32 plan on the long
  * column transforms (L = 2304, 4608), whose column passes are two launches each -- forward half, inverse half, the

@@ -222,8 +222,8 @@ class DeconvPlan:
     def strategy(self):
         a, b, c, d = _i(), _i(), _i(), _i()
         check(lib.rl_deconv_strategy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
-        return {'separable': bool(a.value), 'real_psf_spectrum': bool(b.value), 'split_column_pass': bool(c.value),
-                'frame_pairs': bool(d.value)}
+        return {'separable': a.value == 1, 'direct_stencil': a.value == 2, 'real_psf_spectrum': bool(b.value),
+                'split_column_pass': bool(c.value), 'frame_pairs': bool(d.value)}
 
     def set_object(self, obj, total_brightness=None):
         obj = as_f64(obj).reshape(self.B, self.ny, self.nx)

@@ -318,6 +318,7 @@ struct rl_deconv {
     void *sep_u = nullptr, *sep_v = nullptr;   // [V][py], [V][px] in the plan's dtype
     void *sep_uf = nullptr, *sep_vf = nullptr; // flipped, zero padded to multiples of 8: the one-kernel form's taps
     bool sep_one = false;                      // both passes in one kernel (RLSTED_SEP_ONE, see deconv_build)
+    bool sep_direct = false;                   // the one-kernel form as a direct 2-D stencil: PSFs that are not rank 1 (RLSTED_DIRECT)
     int sep2d_(int mode, const void* in, const void* aux, const void* nrm, void* dst, int frames) {
         const bool multi = mode == SEP_SUM_ || mode == SEP_UPDATE_;
         for (int f0 = 0; f0 < frames; f0 += 65535) {
@@ -1226,6 +1227,33 @@ static int deconv_build(rl_deconv* h, const double* psfs) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
     }
+    // ---- ... or a direct 2-D stencil when the views are small but not rank 1 (sep_kernels.hip k_sep2d DIRECT): py * px multiply-adds per
+    // pixel and view, all of one sign for a non-negative PSF -- the relative accuracy an FFT convolution cannot give a dark region
+    // (DESIGN.md section 3b).  RLSTED_DIRECT: 0 never, 1 (default) up to RLSTED_DIRECT_MAX_TAPS = 49 taps (where it is also the faster
+    // path), 2 whenever the tile fits LDS (f32 plans on sparse samples with PSFs up to ~15 x 15: 2x the FFT path's time at 11 x 11).
+    {
+        const int direct_mode = getenv("RLSTED_DIRECT") ? atoi(getenv("RLSTED_DIRECT")) : 1;
+        const int direct_max = getenv("RLSTED_DIRECT_MAX_TAPS") ? atoi(getenv("RLSTED_DIRECT_MAX_TAPS")) : 49;
+        if (!h->sep && sep_mode > 0 && direct_mode > 0 && (direct_mode > 1 || h->py * h->px <= direct_max) && h->py * h->px <= 1024 &&
+            direct2d_fits(h->dtype, h->py, h->px, (int)V)) {
+            const size_t py = h->py, px = h->px, pyp = (py + 7) / 8 * 8;
+            std::vector<double> f(V * px * pyp, 0.0);
+            for (size_t v = 0; v < V; ++v)
+                for (size_t l = 0; l < px; ++l)
+                    for (size_t k = 0; k < py; ++k) f[(v * px + l) * pyp + k] = psfs[(v * py + (py - 1 - k)) * px + (px - 1 - l)];
+            HIP_TRY(hipMalloc(&h->sep_uf, f.size() * es));
+            if (h->dtype == RL_F64) {
+                HIP_TRY(hipMemcpy(h->sep_uf, f.data(), f.size() * 8, hipMemcpyHostToDevice));
+            } else {
+                std::vector<float> ff(f.begin(), f.end());
+                HIP_TRY(hipMemcpy(h->sep_uf, ff.data(), ff.size() * 4, hipMemcpyHostToDevice));
+            }
+            h->sep = h->sep_one = h->sep_direct = true;      // (sep_vf stays null: that is how sep2d tells the two forms apart)
+            HIP_TRY(aux_fill(h->dtype, h->scratch, V * h->n_img(), 1.0, ctx->stream));
+            RL_TRY(h->sep2d_(SEP_SUM_, h->scratch, nullptr, nullptr, h->norm, 1));      // H_t(ones) through the same stencil (ref:589-592)
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
     if (h->col_split()) {   // (the one-frame parking space of the set-up -> the plan's, unless the stencils took over)
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipFree(h->spec_x));
@@ -1569,7 +1597,7 @@ int rl_deconv_bench_cycles(rl_deconv* h, int k, int reps, int rng_kind, uint64_t
 int rl_deconv_strategy(const rl_deconv* h, int* separable, int* real_psf_spectrum, int* split_column_pass, int* frame_pairs) {
     if (!h) return fail(RL_ERR_INVALID, "handle is NULL");
     if (frame_pairs) *frame_pairs = h->pair ? 1 : 0;
-    if (separable) *separable = h->sep ? 1 : 0;
+    if (separable) *separable = h->sep ? (h->sep_direct ? 2 : 1) : 0;
     if (real_psf_spectrum) *real_psf_spectrum = h->psf_hat_re ? 1 : 0;
     if (split_column_pass) *split_column_pass = !h->sep && !h->pair && h->col_split() ? 1 : 0;
     return RL_OK;

@@ -132,7 +132,10 @@ __device__ __forceinline__ void sep_window8(const T* __restrict__ base, int stri
     }
 }
 
-template <typename T, int MODE, int TH>
+// DIRECT (round 4): the PSF is NOT rank 1 -- no row pass; every output sums px column windows of the input tile, taps
+// uf = [V][px][8 nca]: F[l][k] = p[py-1-k][px-1-l] (flipped both ways, zero padded along k), vf unused.  py * px multiply-adds per
+// pixel, all of one sign for a non-negative PSF: the RELATIVE accuracy the FFT path cannot give a dark region.
+template <typename T, int MODE, int TH, bool DIRECT = false>
 __global__ void __launch_bounds__(256) k_sep2d(const T* __restrict__ in, const T* __restrict__ uf, const T* __restrict__ vf,
                                                const T* __restrict__ aux, const T* __restrict__ norm, T* __restrict__ dst, int ny, int nx,
                                                int py, int px, int V) {
@@ -143,10 +146,14 @@ __global__ void __launch_bounds__(256) k_sep2d(const T* __restrict__ in, const T
     const int nca = (py + 7) / 8, ncb = (px + 7) / 8;
     const int R = TH + 8 * nca, IP = (kColW + 8 * ncb) | 1, TP = kColW + 1;   // rows staged, odd pitches
     T* tin = reinterpret_cast<T*>(smem);                    // [R][IP]  input tile, element (i, j) <-> (y0 - oy + i, x0 - ox + j)
-    T* tmp = tin + (size_t)R * IP;                          // [R][TP]  row-pass results
-    T* ftaps = tmp + (size_t)R * TP;                        // [V][8 nca] then [V][8 ncb]: LDS broadcasts instead of scalar-load latency
-    for (int i = threadIdx.x; i < V * 8 * nca; i += 256) ftaps[i] = uf[i];
-    for (int i = threadIdx.x; i < V * 8 * ncb; i += 256) ftaps[V * 8 * nca + i] = vf[i];
+    T* tmp = tin + (size_t)R * IP;                          // [R][TP]  row-pass results (not DIRECT)
+    T* ftaps = DIRECT ? tmp : tmp + (size_t)R * TP;         // [V][8 nca] then [V][8 ncb] (DIRECT: [V][px][8 nca]): LDS broadcasts instead of scalar-load latency
+    if constexpr (DIRECT) {
+        for (int i = threadIdx.x; i < V * px * 8 * nca; i += 256) ftaps[i] = uf[i];
+    } else {
+        for (int i = threadIdx.x; i < V * 8 * nca; i += 256) ftaps[i] = uf[i];
+        for (int i = threadIdx.x; i < V * 8 * ncb; i += 256) ftaps[V * 8 * nca + i] = vf[i];
+    }
     const int oy = py - 1 - (py - 1) / 2, ox = px - 1 - (px - 1) / 2;
     const int x0 = blockIdx.x * kColW, y0 = blockIdx.y * TH, frame = blockIdx.z, t = threadIdx.x;
     T sum[NI][8];
@@ -168,21 +175,36 @@ __global__ void __launch_bounds__(256) k_sep2d(const T* __restrict__ in, const T
             }
             __syncthreads();
         }
-        const T* fv = ftaps + V * 8 * nca + view * 8 * ncb;
-        for (int w = t; w < R * (kColW / 8); w += 256) {    // lanes along rows: odd pitches keep LDS conflict free
-            const int i = w % R, sgm = w / R;
-            T acc[8];
-            sep_window8(tin + i * IP + sgm * 8, 1, fv, ncb, acc);
+        if constexpr (!DIRECT) {
+            const T* fv = ftaps + V * 8 * nca + view * 8 * ncb;
+            for (int w = t; w < R * (kColW / 8); w += 256) {    // lanes along rows: odd pitches keep LDS conflict free
+                const int i = w % R, sgm = w / R;
+                T acc[8];
+                sep_window8(tin + i * IP + sgm * 8, 1, fv, ncb, acc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tmp[i * TP + sgm * 8 + j] = acc[j];
+                for (int j = 0; j < 8; ++j) tmp[i * TP + sgm * 8 + j] = acc[j];
+            }
+            __syncthreads();
+        } else if (view == 0) {
+            __syncthreads();                                    // the taps are in LDS
         }
-        __syncthreads();
-        const T* fu = ftaps + view * 8 * nca;
+        const T* fu = ftaps + view * (DIRECT ? px : 1) * 8 * nca;
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             const int it = t + 256 * n, c = it % kColW, g = it / kColW;
             T acc[8];
-            sep_window8(tmp + (g * 8) * TP + c, TP, fu, nca, acc);
+            if constexpr (DIRECT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = 0;
+                for (int l = 0; l < px; ++l) {                  // column x0 + c + l - ox of the tile, all its taps
+                    T part[8];
+                    sep_window8(tin + (g * 8) * IP + c + l, IP, fu + l * 8 * nca, nca, part);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += part[j];
+                }
+            } else {
+                sep_window8(tmp + (g * 8) * TP + c, TP, fu, nca, acc);
+            }
             const int x = x0 + c;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -216,35 +238,36 @@ __global__ void __launch_bounds__(256) k_sep2d(const T* __restrict__ in, const T
 }
 
 template <typename T, int TH>
-size_t sep2d_lds(int py, int px, int V) {
+size_t sep2d_lds(int py, int px, int V, bool direct = false) {
     const int nca = (py + 7) / 8, ncb = (px + 7) / 8;
+    if (direct) return ((size_t)(TH + 8 * nca) * ((kColW + 8 * ncb) | 1) + (size_t)V * px * 8 * nca) * sizeof(T);
     return ((size_t)(TH + 8 * nca) * (((kColW + 8 * ncb) | 1) + kColW + 1) + (size_t)V * 8 * (nca + ncb)) * sizeof(T);
 }
-template <typename T, int MODE, int TH>
+template <typename T, int MODE, int TH, bool DIRECT = false>
 hipError_t sep2d_launch(const void* in, const void* uf, const void* vf, const void* aux, const void* norm, void* dst, int frames,
                         int ny, int nx, int py, int px, int V, hipStream_t s) {
     static unsigned long long allowed_devices = 0;   // the attribute is per device: one bit per device id
-    const size_t lds = sep2d_lds<T, TH>(py, px, V);
+    const size_t lds = sep2d_lds<T, TH>(py, px, V, DIRECT);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !(allowed_devices >> dev & 1ull)) {
-        e = hipFuncSetAttribute((const void*)k_sep2d<T, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSep2dMaxLds);
+        e = hipFuncSetAttribute((const void*)k_sep2d<T, MODE, TH, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSep2dMaxLds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) allowed_devices |= 1ull << dev;
     }
     const dim3 grid((unsigned)((nx + kColW - 1) / kColW), (unsigned)((ny + TH - 1) / TH), (unsigned)frames);
-    k_sep2d<T, MODE, TH><<<grid, 256, lds, s>>>((const T*)in, (const T*)uf, (const T*)vf, (const T*)aux, (const T*)norm, (T*)dst, ny, nx, py, px, V);
+    k_sep2d<T, MODE, TH, DIRECT><<<grid, 256, lds, s>>>((const T*)in, (const T*)uf, (const T*)vf, (const T*)aux, (const T*)norm, (T*)dst, ny, nx, py, px, V);
     return hipGetLastError();
 }
-template <typename T, int TH>
+template <typename T, int TH, bool DIRECT = false>
 hipError_t sep2d_t(int mode, const void* in, const void* uf, const void* vf, const void* aux, const void* norm, void* dst, int frames,
                    int ny, int nx, int py, int px, int V, hipStream_t s) {
     switch (mode) {
-        case SEP_STORE: return sep2d_launch<T, SEP_STORE, TH>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
-        case SEP_RATIO: return sep2d_launch<T, SEP_RATIO, TH>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
-        case SEP_SUM: return sep2d_launch<T, SEP_SUM, TH>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
-        case SEP_UPDATE: return sep2d_launch<T, SEP_UPDATE, TH>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
+        case SEP_STORE: return sep2d_launch<T, SEP_STORE, TH, DIRECT>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
+        case SEP_RATIO: return sep2d_launch<T, SEP_RATIO, TH, DIRECT>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
+        case SEP_SUM: return sep2d_launch<T, SEP_SUM, TH, DIRECT>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
+        case SEP_UPDATE: return sep2d_launch<T, SEP_UPDATE, TH, DIRECT>(in, uf, vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -313,11 +336,12 @@ static int sep_th32() {
     static const int th = getenv("RLSTED_SEP_TH") ? atoi(getenv("RLSTED_SEP_TH")) : 32;
     return th == 64 ? 64 : 32;
 }
-size_t sep2d_lds_bytes(int dtype, int py, int px, int V) {
-    if (dtype != DT_F32) return sep2d_lds<double, 32>(py, px, V);
-    return sep_th32() == 64 ? sep2d_lds<float, 64>(py, px, V) : sep2d_lds<float, 32>(py, px, V);
+size_t sep2d_lds_bytes(int dtype, int py, int px, int V, bool direct = false) {
+    if (dtype != DT_F32) return sep2d_lds<double, 32>(py, px, V, direct);
+    return sep_th32() == 64 ? sep2d_lds<float, 64>(py, px, V, direct) : sep2d_lds<float, 32>(py, px, V, direct);
 }
 bool sep2d_fits(int dtype, int py, int px, int V) { return sep2d_lds_bytes(dtype, py, px, V) <= kSep2dMaxLds; }
+bool direct2d_fits(int dtype, int py, int px, int V) { return sep2d_lds_bytes(dtype, py, px, V, true) <= kSep2dMaxLds; }
 // the two-pass form: the column pass stages (32 + py - 1) rows of 64 columns, the row pass 256 + px - 1 values
 bool sep_two_pass_fits(int dtype, int py, int px) {
     const size_t es = dtype == DT_F32 ? 4 : 8;
@@ -326,6 +350,12 @@ bool sep_two_pass_fits(int dtype, int py, int px) {
 hipError_t sep2d(int dtype, int mode, const void* in, const void* taps_uf, const void* taps_vf, const void* aux, const void* norm,
                  void* dst, int frames, int ny, int nx, int py, int px, int V, hipStream_t s) {
     if (frames < 1) return hipSuccess;
+    if (taps_vf == nullptr) {   // the direct 2-D stencil: taps_uf = [V][px][8 * ceil(py / 8)]
+        if (frames > 65535 || !direct2d_fits(dtype, py, px, V)) return hipErrorInvalidValue;
+        if (dtype != DT_F32) return sep2d_t<double, 32, true>(mode, in, taps_uf, nullptr, aux, norm, dst, frames, ny, nx, py, px, V, s);
+        return sep_th32() == 64 ? sep2d_t<float, 64, true>(mode, in, taps_uf, nullptr, aux, norm, dst, frames, ny, nx, py, px, V, s)
+                                : sep2d_t<float, 32, true>(mode, in, taps_uf, nullptr, aux, norm, dst, frames, ny, nx, py, px, V, s);
+    }
     if (frames > 65535 || !sep2d_fits(dtype, py, px, V)) return hipErrorInvalidValue;
     if (dtype != DT_F32) return sep2d_t<double, 32>(mode, in, taps_uf, taps_vf, aux, norm, dst, frames, ny, nx, py, px, V, s);
     return sep_th32() == 64 ? sep2d_t<float, 64>(mode, in, taps_uf, taps_vf, aux, norm, dst, frames, ny, nx, py, px, V, s)

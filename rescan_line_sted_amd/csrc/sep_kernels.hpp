@@ -15,6 +15,9 @@ hipError_t sep_cols(int dtype, int mode, const void* tmp, const void* taps_u, co
 // FLIPPED (f[k] = taps[n-1-k]) and zero padded.  STORE / RATIO: in [frames], dst [frames*V]; SUM / UPDATE: in
 // [frames*V], dst [frames].  sep2d_fits: the tile fits the 160 KB of LDS.
 bool sep2d_fits(int dtype, int py, int px, int V);
+// the direct 2-D stencil for PSFs that are not rank 1 (sep2d with taps_vf == nullptr, taps_uf = [V][px][8*ceil(py/8)]:
+// F[l][k] = p[py-1-k][px-1-l], zero padded along k): the input tile and the taps fit LDS
+bool direct2d_fits(int dtype, int py, int px, int V);
 // the two-pass form (sep_rows + sep_cols) fits LDS: py up to 609 taps in f32, 289 in f64 (the plan falls back to the FFT path beyond)
 bool sep_two_pass_fits(int dtype, int py, int px);
 hipError_t sep2d(int dtype, int mode, const void* in, const void* taps_uf, const void* taps_vf, const void* aux, const void* norm,

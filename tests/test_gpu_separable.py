@@ -178,3 +178,85 @@ def test_long_column_stencils_raise_their_lds_limit_or_fall_back(lib, dtype, py,
     assert max_rel(sep.forward(x), fft.forward(x)) < (1e-12 if dtype == 'f64' else 2e-6)
     d = orc.Deconvolver(psf)
     assert max_rel(sep.forward(x)[0, 0], d.H(x[:1])[0][0]) < (1e-12 if dtype == 'f64' else 2e-6)
+
+
+# ------------------------------------------------------------------ the direct 2-D stencil (PSFs that are not rank 1)
+def _direct_plan(lib, mode, psfs, B, ny, nx, dtype, monkeypatch):
+    monkeypatch.setenv('RLSTED_DIRECT', str(mode))
+    try:
+        return lib.DeconvPlan(psfs, B, ny, nx, dtype=dtype)
+    finally:
+        monkeypatch.delenv('RLSTED_DIRECT')
+
+
+@pytest.mark.parametrize('py,px,V,shape', [(3, 5, 2, (40, 70)), (7, 7, 1, (128, 128)), (11, 9, 3, (61, 300)), (2, 6, 2, (33, 33)),
+                                           (15, 13, 1, (200, 90)), (8, 4, 4, (17, 250))])
+def test_direct_stencil_matches_fft_strategy_and_oracle(lib, py, px, V, shape, monkeypatch):
+    """PSFs that are small but not rank 1 run as a direct 2-D stencil (sep_kernels.hip k_sep2d DIRECT; the default up to 49 taps,
+    RLSTED_DIRECT=2 beyond): H, H_t with and without the normaliser, the noiseless image, the Poisson draws from it and 25 RL
+    iterations against the FFT strategy of the same library and against the oracle -- odd / even / two-row taps, 1-4 views, tiles
+    that do not fill."""
+    rng = np.random.default_rng(py * 100 + px)
+    psfs = [rng.random((1, py, px)) + 0.05 for _ in range(V)]
+    B, (ny, nx) = 2, shape
+    obj = rng.random((B, ny, nx)) * 50
+    d = _direct_plan(lib, 2, psfs, B, ny, nx, 'f64', monkeypatch)
+    fft = _direct_plan(lib, 0, psfs, B, ny, nx, 'f64', monkeypatch)
+    assert d.strategy()['direct_stencil'] and not d.strategy()['separable']
+    assert not fft.strategy()['direct_stencil'] and not fft.strategy()['separable']
+    if py * px <= 49:
+        assert lib.DeconvPlan(psfs, B, ny, nx, dtype='f64').strategy()['direct_stencil']     # the default
+    assert max_rel(d.forward(obj), fft.forward(obj)) < 1e-12
+    y = rng.random((B, V, ny, nx))
+    for normalize in (True, False):
+        assert max_rel(d.adjoint(y, normalize), fft.adjoint(y, normalize)) < 1e-12
+    for p in (d, fft):
+        p.set_object(obj, 1e7)
+        p.simulate(seed=9)
+    assert max_rel(d.noiseless(), fft.noiseless()) < 1e-12
+    assert np.array_equal(d.measurement(), fft.measurement())
+    for p in (d, fft):
+        p.iterate(25)
+    assert max_rel(d.estimate(), fft.estimate()) < 1e-11
+    o = orc.Deconvolver(psfs)
+    o.create_data_from_object(obj[:1], noisy_measurement=[m[None] for m in d.measurement()[0]])
+    for _ in range(25):
+        o.iterate()
+    assert max_rel(d.estimate()[0], o.estimate[0]) < 1e-10
+    f32 = _direct_plan(lib, 2, psfs, B, ny, nx, 'f32', monkeypatch)
+    assert f32.strategy()['direct_stencil']
+    f32.set_measurement(d.measurement())
+    f32.iterate(25)
+    assert max_rel(f32.estimate(), d.estimate()) < 1e-5
+
+
+def test_direct_stencil_keeps_f32_plans_accurate_on_dark_backgrounds(lib, monkeypatch):
+    """What the direct stencil is for beyond speed: sparse emitters on a black background under a narrow, non-separable PSF
+    (tests/test_gpu_parity.py::test_dark_background_narrow_psf_stays_finite).  The FFT path's f32 predictions of the dark region are
+    rounding noise (finite, but 1e-5 ... 4e-5 of the maximum from the float64 plan, and counted by rl_deconv_unresolved); the
+    stencil sums non-negative terms only, so every prediction keeps its relative accuracy: f32 within 3e-6 of float64."""
+    rng = np.random.default_rng(77)
+    ny = nx = 256
+    obj = np.zeros((2, ny, nx))
+    for b in range(2):
+        obj[b, rng.integers(8, ny - 8, 30), rng.integers(8, nx - 8, 30)] = rng.random(30) + 0.5
+    yy, xx = np.mgrid[-4:5, -4:5]
+    u, w = 0.866 * xx + 0.5 * yy, -0.5 * xx + 0.866 * yy
+    psf = [np.exp(-0.5 * ((u / 1.6) ** 2 + (w / 0.8) ** 2))[None]]
+    p64 = _direct_plan(lib, 0, psf, 2, ny, nx, 'f64', monkeypatch)
+    p64.set_object(obj, 3e3)
+    p64.simulate(seed=9)
+    meas = p64.measurement()
+    p64.iterate(12)
+    ref = p64.estimate()
+    err = {}
+    for mode in (0, 2):
+        p32 = _direct_plan(lib, mode, psf, 2, ny, nx, 'f32', monkeypatch)
+        assert p32.strategy()['direct_stencil'] == (mode == 2)
+        p32.set_measurement(meas)
+        p32.iterate(12)
+        e = p32.estimate()
+        assert np.isfinite(e).all() and e.min() >= 0
+        err[mode] = max_rel(e, ref)
+    print('f32 against float64, 12 iterations: FFT path %.2e, direct stencil %.2e' % (err[0], err[2]))
+    assert err[2] < 3e-6 and err[2] < 0.3 * err[0]
