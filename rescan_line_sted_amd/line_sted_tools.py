@@ -242,8 +242,9 @@ class Deconvolver:
             self._unresolved_warned = True
             warnings.warn('%d row segments of the Richardson-Lucy iterations met a prediction H(estimate) <= 0: the reference would '
                           'have divided by zero (inf, nan); these pixels were kept neutral.%s' % (
-                              n, ' The float32 plan (RLSTED_DTYPE=f32) cannot resolve the predictions of dark regions: use the float64 '
-                              'default for such data.' if self.dtype == 'f32' else ''), RuntimeWarning, stacklevel=3)
+                              n, ' The float32 plan (RLSTED_DTYPE=f32) cannot resolve the predictions of dark regions through its transforms: '
+                              'use the float64 default for such data, or -- PSFs up to about 15 x 15 -- the direct stencil (RLSTED_DIRECT=2).'
+                              if self.dtype == 'f32' else ''), RuntimeWarning, stacklevel=3)
 
     @property
     def estimate(self):
